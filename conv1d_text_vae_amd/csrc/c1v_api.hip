@@ -1,0 +1,112 @@
+// C-ABI entry points that map the layer-level ops (conv / deconv / dense forward, dgrad, wgrad) onto the GEMM
+// engine of c1v_gemm.hip, plus error / version / device-info plumbing.  Every shape is checked here, on the host,
+// before anything is launched.
+#include <stdarg.h>
+#include "c1v_common.h"
+
+static thread_local std::string g_err;
+
+void c1v_set_error(const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+}
+
+extern "C" const char* c1v_last_error(void) { return g_err.c_str(); }
+extern "C" int c1v_version(void) { return 100; }
+
+extern "C" int c1v_device_info(int32_t device, int32_t* info4) {
+    C1V_REQUIRE(info4, "device_info: null argument");
+    hipDeviceProp_t prop;
+    hipError_t e = hipGetDeviceProperties(&prop, device);
+    C1V_REQUIRE(e == hipSuccess, "device_info: %s", hipGetErrorString(e));
+    info4[0] = prop.multiProcessorCount;
+    info4[1] = (int32_t)prop.maxSharedMemoryPerMultiProcessor;
+    info4[2] = prop.warpSize;
+    int arch = 0;
+    sscanf(prop.gcnArchName, "gfx%d", &arch);
+    info4[3] = arch;
+    return 0;
+}
+
+static int check_operand_seq(const c1v_seq& s, const char* what) {
+    C1V_REQUIRE(s.data != nullptr, "%s: null buffer", what);
+    C1V_REQUIRE(s.dtype == C1V_F32 || s.dtype == C1V_BF16, "%s: bad dtype %d", what, s.dtype);
+    C1V_REQUIRE(s.batch > 0 && s.len > 0 && s.off >= 0 && s.c > 0 && s.c <= s.cp, "%s: bad descriptor", what);
+    C1V_REQUIRE(s.cp % 32 == 0, "%s: operand row pitch (%d) must be a multiple of 32 elements", what, s.cp);
+    C1V_REQUIRE(s.bstride % s.cp == 0 && s.bstride >= (int64_t)(s.off + s.len) * s.cp, "%s: sample stride must be whole rows covering off+len", what);
+    return 0;
+}
+
+// ---- conv / deconv forward and dgrad ------------------------------------------------------------------
+static int conv_common(const c1v_conv1d_args* a, void* stream, const char* what) {
+    C1V_REQUIRE(a && a->w_op, "%s: null argument", what);
+    if (check_operand_seq(a->x, what)) return -1;
+    C1V_REQUIRE(a->k > 0 && a->n_rows > 0 && a->n_out > 0 && a->a_off >= 0, "%s: bad shape k=%d n_rows=%d n_out=%d", what, a->k, a->n_rows, a->n_out);
+    const int pitch = (int)(a->x.bstride / a->x.cp);
+    // every window read must stay inside the allocation: the last sample may run into the slack rows
+    C1V_REQUIRE(a->a_off + a->n_rows + a->k - 1 <= pitch + C1V_SLACK_ROWS, "%s: window (a_off=%d n_rows=%d k=%d) overruns the sample pitch %d", what, a->a_off, a->n_rows, a->k, pitch);
+    const bool pairs = a->epi.row_mode == C1V_ROW_POOL2 || a->epi.row_mode == C1V_ROW_PAIRSUM;
+    const int Le = pairs ? ((a->n_rows + 1) & ~1) : a->n_rows;
+    C1V_REQUIRE(a->a_off + Le + a->k - 1 <= pitch + C1V_SLACK_ROWS, "%s: padded row enumeration overruns the sample pitch", what);
+    const int es = c1v_esize(a->x.dtype);
+    NtParams p{};
+    p.A = (const char*)a->x.data; p.a_bstride_b = a->x.bstride * es; p.lda_b = (int64_t)a->x.cp * es; p.a_off = a->a_off;
+    p.W = (const char*)a->w_op; p.ldw_b = (int64_t)a->k * a->x.cp * es; p.Kb = p.ldw_b;
+    const int64_t M = (int64_t)a->x.batch * Le;
+    C1V_REQUIRE(M < (1ll << 31), "%s: too many rows", what);
+    if (c1v_fill_epi(a->epi, p.e, (int)M, Le, a->n_rows, a->n_out)) return -1;
+    return c1v_launch_nt(a->x.dtype, p, (hipStream_t)stream);
+}
+extern "C" int c1v_conv1d_fwd(const c1v_conv1d_args* a, void* s) { return conv_common(a, s, "conv1d_fwd"); }
+extern "C" int c1v_conv1d_dgrad(const c1v_conv1d_args* a, void* s) { return conv_common(a, s, "conv1d_dgrad"); }
+extern "C" int c1v_deconv1d_fwd(const c1v_conv1d_args* a, void* s) {
+    C1V_REQUIRE(a, "deconv1d_fwd: null argument");
+    C1V_REQUIRE(a->x.off == a->k - 1 && a->a_off == 0, "deconv1d_fwd: the input buffer must carry k-1 zero rows in front (off=%d, k=%d)", a->x.off, a->k);
+    return conv_common(a, s, "deconv1d_fwd");
+}
+extern "C" int c1v_deconv1d_dgrad(const c1v_conv1d_args* a, void* s) { return conv_common(a, s, "deconv1d_dgrad"); }
+
+// ---- dense forward / dgrad -----------------------------------------------------------------------------
+static int dense_common(const c1v_dense_args* a, void* stream, const char* what) {
+    C1V_REQUIRE(a && a->a && a->w_op, "%s: null argument", what);
+    C1V_REQUIRE(a->dtype == C1V_F32 || a->dtype == C1V_BF16, "%s: bad dtype", what);
+    C1V_REQUIRE(a->rows > 0 && a->K > 0 && a->n_out > 0 && a->lda >= a->K && a->ldw >= a->K, "%s: bad shape rows=%d K=%d n_out=%d", what, a->rows, a->K, a->n_out);
+    const int es = c1v_esize(a->dtype);
+    C1V_REQUIRE((a->K * es) % 16 == 0, "%s: K (%d) must be a whole number of 16-byte chunks", what, a->K);
+    NtParams p{};
+    p.A = (const char*)a->a; p.a_bstride_b = a->lda * es; p.lda_b = a->lda * es; p.a_off = 0;
+    p.W = (const char*)a->w_op; p.ldw_b = a->ldw * es; p.Kb = (int64_t)a->K * es;
+    C1V_REQUIRE(a->epi.row_mode == C1V_ROW_STORE || a->epi.row_mode == C1V_ROW_UNPOOL, "%s: dense epilogue supports STORE / UNPOOL only", what);
+    if (c1v_fill_epi(a->epi, p.e, a->rows, 1, 1, a->n_out)) return -1;
+    return c1v_launch_nt(a->dtype, p, (hipStream_t)stream);
+}
+extern "C" int c1v_dense_fwd(const c1v_dense_args* a, void* s) { return dense_common(a, s, "dense_fwd"); }
+extern "C" int c1v_dense_dgrad(const c1v_dense_args* a, void* s) { return dense_common(a, s, "dense_dgrad"); }
+
+// ---- wgrad -------------------------------------------------------------------------------------------------
+extern "C" int c1v_wgrad(const c1v_wgrad_args* a, void* stream) {
+    C1V_REQUIRE(a && a->a && a->d && a->out, "wgrad: null argument");
+    C1V_REQUIRE(a->dtype == C1V_F32 || a->dtype == C1V_BF16, "wgrad: bad dtype");
+    C1V_REQUIRE(a->I > 0 && a->J > 0 && a->I <= a->lda && a->J <= a->ldd, "wgrad: bad shape I=%d J=%d", a->I, a->J);
+    C1V_REQUIRE(a->r_end > a->r_begin && a->taps > 0 && a->splits > 0, "wgrad: empty row range");
+    C1V_REQUIRE(a->r_begin + a->a_shift0 >= 0, "wgrad: first A row would be negative");
+    const int es = c1v_esize(a->dtype);
+    const int per16 = 16 / es;
+    TnParams p{};
+    p.A = (const char*)a->a; p.lda_b = a->lda * es; p.I = a->I; p.Ia = (int)(c1v_cdiv(a->I, per16) * per16);
+    p.D = (const char*)a->d; p.ldd_b = a->ldd * es; p.J = a->J; p.Ja = (int)(c1v_cdiv(a->J, per16) * per16);
+    C1V_REQUIRE(p.Ia <= a->lda && p.Ja <= a->ldd, "wgrad: rows must be padded to 16-byte chunks");
+    p.r_begin = a->r_begin; p.r_end = a->r_end;
+    const int br = a->dtype == C1V_F32 ? 32 : 64;
+    p.rows_per_split = c1v_cdiv(c1v_cdiv(a->r_end - a->r_begin, a->splits), br) * br;
+    p.a_shift0 = a->a_shift0; p.taps = a->taps; p.flip = a->flip; p.tap_stride = a->tap_stride; p.si = a->si; p.sj = a->sj;
+    p.out = a->out; p.slab_stride = a->slab_stride; p.splits = a->splits;
+    return c1v_launch_tn(a->dtype, p, (hipStream_t)stream);
+}
+extern "C" int c1v_conv1d_wgrad(const c1v_wgrad_args* a, void* s) { return c1v_wgrad(a, s); }
+extern "C" int c1v_deconv1d_wgrad(const c1v_wgrad_args* a, void* s) { return c1v_wgrad(a, s); }
+extern "C" int c1v_dense_wgrad(const c1v_wgrad_args* a, void* s) { return c1v_wgrad(a, s); }

@@ -1,0 +1,89 @@
+// Shared device/host helpers of libc1dvae (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+#include "../../include/c1dvae.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef unsigned short bf16_raw;
+
+#define C1V_LDS_PTR(T, p) ((__attribute__((address_space(3))) T*)(p))
+
+__device__ __forceinline__ float bf16_to_f32(bf16_raw h) { return __uint_as_float(((uint32_t)h) << 16); }
+__device__ __forceinline__ bf16_raw f32_to_bf16(float f) {
+    __bf16 b = (__bf16)f;                       // v_cvt_pk_bf16_f32: round-to-nearest-even, NaN stays NaN
+    return __builtin_bit_cast(bf16_raw, b);
+}
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+}
+
+template <typename T> struct ElemTraits;
+template <> struct ElemTraits<float> {
+    static constexpr int kDtype = C1V_F32;
+    static constexpr int kPer16B = 4;
+    __device__ static __forceinline__ float load(const void* p, int64_t i) { return ((const float*)p)[i]; }
+    __device__ static __forceinline__ void store(void* p, int64_t i, float v) { ((float*)p)[i] = v; }
+};
+template <> struct ElemTraits<bf16_raw> {
+    static constexpr int kDtype = C1V_BF16;
+    static constexpr int kPer16B = 8;
+    __device__ static __forceinline__ float load(const void* p, int64_t i) { return bf16_to_f32(((const bf16_raw*)p)[i]); }
+    __device__ static __forceinline__ void store(void* p, int64_t i, float v) { ((bf16_raw*)p)[i] = f32_to_bf16(v); }
+};
+
+__device__ __forceinline__ float load_any(const void* p, int dtype, int64_t i) {
+    return dtype == C1V_F32 ? ((const float*)p)[i] : bf16_to_f32(((const bf16_raw*)p)[i]);
+}
+__device__ __forceinline__ void store_any(void* p, int dtype, int64_t i, float v) {
+    if (dtype == C1V_F32) ((float*)p)[i] = v; else ((bf16_raw*)p)[i] = f32_to_bf16(v);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// ---- host side -------------------------------------------------------------------------------------
+void c1v_set_error(const char* fmt, ...);
+#define C1V_REQUIRE(cond, ...) do { if (!(cond)) { c1v_set_error(__VA_ARGS__); return -1; } } while (0)
+#define C1V_LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) { \
+        c1v_set_error("%s:%d launch failed: %s", __FILE__, __LINE__, hipGetErrorString(e_)); return -2; } } while (0)
+
+static inline int c1v_esize(int dtype) { return dtype == C1V_F32 ? 4 : 2; }
+__host__ __device__ static inline int64_t c1v_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// device-side copy of c1v_epilogue plus the row enumeration of the launch
+struct EpiDev {
+    const float* bias; int relu; int row_mode; int reshape_w; int exp2;
+    void* dst; int dst_dtype; int64_t dst_bstride; int dst_off, dst_len, dst_cp, dst_c;
+    const void* act; int act_dtype; int64_t act_bstride; int act_off, act_cp, act_rowmul; float act_scale;
+    uint8_t* sel; int64_t sel_bstride; int sel_cp;
+    const uint8_t* keep; float keep_scale;
+    int M, Le, nrows, N;
+};
+
+struct NtParams {
+    const char* A; int64_t a_bstride_b; int64_t lda_b; int a_off;   // A row(m): b=m/Le,u=m%Le -> A + b*a_bstride_b + (a_off+u)*lda_b
+    const char* W; int64_t ldw_b;
+    int64_t Kb;                                                      // K in bytes
+    EpiDev e;
+};
+
+struct TnParams {
+    const char* A; int64_t lda_b; int I; int Ia;     // Ia = readable columns (multiple of 16 bytes)
+    const char* D; int64_t ldd_b; int J; int Ja;
+    int64_t r_begin, r_end; int64_t rows_per_split;
+    int a_shift0; int taps; int flip; int64_t tap_stride, si, sj;
+    float* out; int64_t slab_stride; int splits;
+};
+
+int c1v_launch_nt(int dtype, const NtParams& p, hipStream_t st);
+int c1v_launch_tn(int dtype, const TnParams& p, hipStream_t st);
+int c1v_fill_epi(const c1v_epilogue& e, EpiDev& d, int M, int Le, int nrows, int N);

@@ -1,0 +1,416 @@
+// HBM-bound kernels of libc1dvae: operand packing, latent head, bias-gradient column sums, gradient finalize,
+// Nadam + global-norm clip, EOS truncation, Philox RNG.  All are grid-stride, coalesced, and reduction orders are
+// fixed (no float atomics) so that two runs of a step are bit-identical.
+#include "c1v_common.h"
+
+// ------------------------------------------------------------------------------------------------------
+// input packing
+// ------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void pack_input_kernel(const float* __restrict__ src, int T_len, int C, c1v_seq dst) {
+    // one thread per (row, padded channel): writes zeros into the channel padding as well
+    const int64_t total = (int64_t)dst.batch * T_len * dst.cp;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % dst.cp);
+        const int64_t row = i / dst.cp;
+        const int t = (int)(row % T_len);
+        const int64_t b = row / T_len;
+        const float v = c < C ? src[row * C + c] : 0.0f;
+        ElemTraits<T>::store(dst.data, b * dst.bstride + (int64_t)(dst.off + t) * dst.cp + c, v);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gather_input_kernel(const float* __restrict__ table, int64_t ld, const int* __restrict__ ids,
+                                                           int T_len, int C, c1v_seq dst) {
+    const int64_t total = (int64_t)dst.batch * T_len * dst.cp;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % dst.cp);
+        const int64_t row = i / dst.cp;
+        const int t = (int)(row % T_len);
+        const int64_t b = row / T_len;
+        const int id = ids[row];
+        const float v = (c < C && id >= 0) ? table[(int64_t)id * ld + c] : 0.0f;
+        ElemTraits<T>::store(dst.data, b * dst.bstride + (int64_t)(dst.off + t) * dst.cp + c, v);
+    }
+}
+
+static unsigned grid_for(int64_t n) {
+    int64_t g = c1v_cdiv(n, 256);
+    return (unsigned)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
+}
+
+static int check_seq(const c1v_seq& s, const char* what) {
+    C1V_REQUIRE(s.data != nullptr, "%s: null buffer", what);
+    C1V_REQUIRE(s.batch > 0 && s.cp > 0 && s.len > 0 && s.off >= 0 && s.c > 0 && s.c <= s.cp, "%s: bad descriptor", what);
+    C1V_REQUIRE(s.bstride >= (int64_t)(s.off + s.len) * s.cp, "%s: sample stride too small", what);
+    C1V_REQUIRE(s.dtype == C1V_F32 || s.dtype == C1V_BF16, "%s: bad dtype", what);
+    return 0;
+}
+
+extern "C" int c1v_pack_input(const c1v_pack_input_args* a, void* stream) {
+    C1V_REQUIRE(a && a->src, "pack_input: null argument");
+    if (check_seq(a->dst, "pack_input dst")) return -1;
+    C1V_REQUIRE(a->T > 0 && a->T <= a->dst.len && a->C > 0 && a->C <= a->dst.cp, "pack_input: shape mismatch (T=%d C=%d)", a->T, a->C);
+    const int64_t total = (int64_t)a->dst.batch * a->T * a->dst.cp;
+    if (a->dst.dtype == C1V_F32) hipLaunchKernelGGL(pack_input_kernel<float>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, a->src, a->T, a->C, a->dst);
+    else hipLaunchKernelGGL(pack_input_kernel<bf16_raw>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, a->src, a->T, a->C, a->dst);
+    C1V_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int c1v_gather_input(const c1v_gather_input_args* a, void* stream) {
+    C1V_REQUIRE(a && a->table && a->ids, "gather_input: null argument");
+    if (check_seq(a->dst, "gather_input dst")) return -1;
+    C1V_REQUIRE(a->T > 0 && a->T <= a->dst.len && a->C > 0 && a->C <= a->dst.cp && a->ld >= a->C, "gather_input: shape mismatch");
+    const int64_t total = (int64_t)a->dst.batch * a->T * a->dst.cp;
+    if (a->dst.dtype == C1V_F32) hipLaunchKernelGGL(gather_input_kernel<float>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, a->table, a->ld, a->ids, a->T, a->C, a->dst);
+    else hipLaunchKernelGGL(gather_input_kernel<bf16_raw>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, a->table, a->ld, a->ids, a->T, a->C, a->dst);
+    C1V_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// weight operand copies (descriptor table on the device; blockIdx.y = descriptor)
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pack_weights_kernel(const c1v_pack_desc* __restrict__ descs) {
+    const c1v_pack_desc d = descs[blockIdx.y];
+    const int64_t total = (int64_t)d.n_count * d.taps * d.c_count;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        // destination-major enumeration (n, tap', c) -> coalesced writes
+        const int c = (int)(i % d.c_count);
+        const int64_t r = i / d.c_count;
+        const int tp = (int)(r % d.taps);
+        const int n = (int)(r / d.taps);
+        const int tap = d.flip ? d.taps - 1 - tp : tp;
+        const float v = d.src[(int64_t)tap * d.s_tap + (int64_t)c * d.s_c + (int64_t)n * d.s_n];
+        store_any(d.dst, d.dtype, (int64_t)n * d.ldk + (int64_t)tp * d.cp + c, v);
+    }
+}
+
+extern "C" int c1v_pack_weights(const c1v_pack_desc* descs, int32_t n_desc, int64_t max_elems, void* stream) {
+    C1V_REQUIRE(descs && n_desc > 0 && max_elems > 0, "pack_weights: bad argument");
+    dim3 grid(grid_for(max_elems) > 64 ? 64 : grid_for(max_elems), (unsigned)n_desc);
+    hipLaunchKernelGGL(pack_weights_kernel, grid, dim3(256), 0, (hipStream_t)stream, descs);
+    C1V_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// latent head: sampling (:1188-1191), KL (:1202), decoder-input dropout (:1254) and their backward
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void latent_fwd_kernel(c1v_latent_args a) {
+    // one wave per sample
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= a.B) return;
+    const float* m = a.mlv + (int64_t)b * 2 * a.D;
+    const float* lv = m + a.D;
+    float kl = 0.f;
+    for (int d = lane; d < a.D; d += 64) {
+        const float mv = m[d], l = lv[d];
+        const float z = mv + expf(a.std_scale * l) * a.eps[(int64_t)b * a.D + d];
+        kl += 1.0f + l - mv * mv - expf(l);
+        if (a.z_out) a.z_out[(int64_t)b * a.D + d] = z;
+        float zd = z;
+        if (a.keep_d) zd = a.keep_d[(int64_t)b * a.D + d] ? z / a.keep_prob : 0.0f;
+        store_any(a.zd_out, a.dtype, (int64_t)b * a.ldz + d, zd);
+    }
+    kl = wave_sum(kl);
+    if (lane == 0 && a.kl_out) a.kl_out[b] = kl / (float)a.D;
+}
+
+__global__ __launch_bounds__(256) void latent_bwd_kernel(c1v_latent_args a) {
+    const int64_t total = (int64_t)a.B * a.D;
+    const float kc = 1.0f / ((float)a.D * (float)a.B_global);
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int d = (int)(i % a.D);
+        const int64_t b = i / a.D;
+        const float mv = a.mlv[b * 2 * a.D + d], l = a.mlv[b * 2 * a.D + a.D + d];
+        float dz = a.dzd[i];
+        if (a.keep_d) dz = a.keep_d[i] ? dz / a.keep_prob : 0.0f;
+        const float dm = dz + 2.0f * mv * kc;
+        const float dl = dz * a.eps[i] * a.std_scale * expf(a.std_scale * l) + (expf(l) - 1.0f) * kc;
+        store_any(a.dmlv, a.dtype, b * a.ldd + d, dm);
+        store_any(a.dmlv, a.dtype, b * a.ldd + a.D + d, dl);
+    }
+}
+
+extern "C" int c1v_latent_head_fwd(const c1v_latent_args* a, void* stream) {
+    C1V_REQUIRE(a && a->mlv && a->eps && a->zd_out, "latent_head_fwd: null argument");
+    C1V_REQUIRE(a->B > 0 && a->D > 0 && a->ldz >= a->D && a->keep_prob > 0.f, "latent_head_fwd: bad shape");
+    hipLaunchKernelGGL(latent_fwd_kernel, dim3((unsigned)c1v_cdiv(a->B, 4)), dim3(256), 0, (hipStream_t)stream, *a);
+    C1V_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int c1v_latent_head_bwd(const c1v_latent_args* a, void* stream) {
+    C1V_REQUIRE(a && a->mlv && a->eps && a->dzd && a->dmlv, "latent_head_bwd: null argument");
+    C1V_REQUIRE(a->B > 0 && a->D > 0 && a->ldd >= 2 * a->D && a->B_global > 0 && a->keep_prob > 0.f, "latent_head_bwd: bad shape");
+    hipLaunchKernelGGL(latent_bwd_kernel, dim3(grid_for((int64_t)a->B * a->D)), dim3(256), 0, (hipStream_t)stream, *a);
+    C1V_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// column sums (bias gradients): grid (column blocks of 64, splits); each block sums its row range
+// ------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ buf, int64_t rows, int64_t ld, int C,
+                                                     float* __restrict__ out, int64_t slab_stride, int splits) {
+    __shared__ float red[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int rl = threadIdx.x >> 6;
+    const int64_t per = c1v_cdiv(rows, splits);
+    const int64_t r0 = (int64_t)blockIdx.y * per;
+    int64_t r1 = r0 + per; if (r1 > rows) r1 = rows;
+    float s = 0.f;
+    if (c < C) for (int64_t r = r0 + rl; r < r1; r += 4) s += ElemTraits<T>::load(buf, r * ld + c);
+    red[rl][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (rl == 0 && c < C) out[(int64_t)blockIdx.y * slab_stride + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+extern "C" int c1v_colsum(const c1v_colsum_args* a, void* stream) {
+    C1V_REQUIRE(a && a->buf && a->out, "colsum: null argument");
+    C1V_REQUIRE(a->rows > 0 && a->C > 0 && a->ld >= a->C && a->splits > 0, "colsum: bad shape");
+    dim3 grid((unsigned)c1v_cdiv(a->C, 64), (unsigned)a->splits);
+    if (a->dtype == C1V_F32) hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)a->buf, a->rows, a->ld, a->C, a->out, a->slab_stride, a->splits);
+    else hipLaunchKernelGGL(colsum_kernel<bf16_raw>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_raw*)a->buf, a->rows, a->ld, a->C, a->out, a->slab_stride, a->splits);
+    C1V_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// gradient finalize: sum the wgrad / colsum slabs of every parameter segment into the flat gradient
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const float r = (red[0] + red[1]) + (red[2] + red[3]);
+    __syncthreads();
+    return r;
+}
+
+__global__ __launch_bounds__(256) void grad_finalize_kernel(const c1v_seg_desc* __restrict__ segs, float* __restrict__ grad,
+                                                            float* __restrict__ sq_partial) {
+    __shared__ float red[4];
+    const c1v_seg_desc d = segs[blockIdx.y];
+    float sq = 0.f;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < d.count; i += (int64_t)gridDim.x * blockDim.x) {
+        float g = 0.f;
+        if (!d.frozen)
+            for (int s = 0; s < d.splits; ++s)
+                for (int r = 0; r < d.reps; ++r) g += d.slab[(int64_t)s * d.slab_stride + (int64_t)r * d.rep_stride + i];
+        grad[d.offset + i] = g;
+        sq += g * g;
+    }
+    sq = block_sum_256(sq, red);
+    if (threadIdx.x == 0 && sq_partial) sq_partial[blockIdx.y * gridDim.x + blockIdx.x] = sq;
+}
+
+extern "C" int c1v_grad_finalize(const c1v_seg_desc* segs, int32_t n_seg, int64_t max_count, float* grad, float* sq_partial, int32_t n_partial, void* stream) {
+    C1V_REQUIRE(segs && grad && n_seg > 0 && max_count > 0, "grad_finalize: bad argument");
+    unsigned gx = grid_for(max_count); if (gx > 32) gx = 32;
+    C1V_REQUIRE(!sq_partial || n_partial == (int)(gx * n_seg), "grad_finalize: n_partial must be %u", gx * n_seg);
+    hipLaunchKernelGGL(grad_finalize_kernel, dim3(gx, (unsigned)n_seg), dim3(256), 0, (hipStream_t)stream, segs, grad, sq_partial);
+    C1V_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int c1v_grad_finalize_partials(int32_t n_seg, int64_t max_count) {
+    unsigned gx = grid_for(max_count); if (gx > 32) gx = 32;
+    return (int)(gx * n_seg);
+}
+
+__global__ __launch_bounds__(256) void sqnorm_partial_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ sq_partial) {
+    __shared__ float red[4];
+    float sq = 0.f;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) { const float g = x[i]; sq += g * g; }
+    sq = block_sum_256(sq, red);
+    if (threadIdx.x == 0) sq_partial[blockIdx.x] = sq;
+}
+extern "C" int c1v_sqnorm_partial(const float* x, int64_t n, float* sq_partial, int32_t n_partial, void* stream) {
+    C1V_REQUIRE(x && sq_partial && n > 0 && n_partial > 0 && n_partial <= 2048, "sqnorm_partial: bad argument");
+    hipLaunchKernelGGL(sqnorm_partial_kernel, dim3((unsigned)n_partial), dim3(256), 0, (hipStream_t)stream, x, n, sq_partial);
+    C1V_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Nadam (Keras 2.2 `Nadam.get_updates`, reference :1329) with global-norm clipping (`clip_norm`)
+// ------------------------------------------------------------------------------------------------------
+// state (device): [0] = iterations (as double), [1] = m_schedule, [2] = lr
+__global__ void nadam_advance_kernel(double* __restrict__ state, float* __restrict__ sched, double beta1, double beta2, double decay) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const double t = state[0] + 1.0;
+    const double mu_t = beta1 * (1.0 - 0.5 * pow(0.96, t * decay));
+    const double mu_t1 = beta1 * (1.0 - 0.5 * pow(0.96, (t + 1.0) * decay));
+    const double m_new = state[1] * mu_t;
+    const double m_next = m_new * mu_t1;
+    sched[0] = (float)state[2];
+    sched[1] = (float)mu_t;
+    sched[2] = (float)mu_t1;
+    sched[3] = (float)(1.0 - m_new);
+    sched[4] = (float)(1.0 - m_next);
+    sched[5] = (float)(1.0 - pow(beta2, t));
+    sched[6] = (float)t;
+    sched[7] = 0.f;
+    state[0] = t;
+    state[1] = m_new;
+}
+extern "C" int c1v_nadam_advance(double* state, float* sched, void* stream) {
+    C1V_REQUIRE(state && sched, "nadam_advance: null argument");
+    hipLaunchKernelGGL(nadam_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, state, sched, 0.9, 0.999, 0.004);
+    C1V_LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ __launch_bounds__(256) void nadam_kernel(c1v_nadam_args a) {
+    __shared__ float red[4];
+    // every block reduces the (small) partial array in the same order -> identical clip scale everywhere
+    float sq = 0.f;
+    for (int i = threadIdx.x; i < a.n_partial; i += 256) sq += a.sq_partial[i];
+    sq = block_sum_256(sq, red);
+    const float norm = sqrtf(sq) * a.grad_scale;
+    float scale = a.grad_scale;
+    if (a.clipnorm > 0.f && norm >= a.clipnorm) scale *= a.clipnorm / norm;
+    if (a.norm_out && blockIdx.x == 0 && threadIdx.x == 0) a.norm_out[0] = norm;
+    const float lr = a.sched[0], mu_t = a.sched[1], mu_t1 = a.sched[2], om_new = a.sched[3], om_next = a.sched[4], ob2t = a.sched[5];
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float g = a.g[i] * scale;
+        const float g_prime = g / om_new;
+        const float m_t = a.beta1 * a.m[i] + (1.0f - a.beta1) * g;
+        const float m_t_prime = m_t / om_next;
+        const float v_t = a.beta2 * a.v[i] + (1.0f - a.beta2) * g * g;
+        const float v_t_prime = v_t / ob2t;
+        const float m_bar = (1.0f - mu_t) * g_prime + mu_t1 * m_t_prime;
+        a.p[i] = a.p[i] - lr * m_bar / (sqrtf(v_t_prime) + a.eps);
+        a.m[i] = m_t;
+        a.v[i] = v_t;
+    }
+}
+extern "C" int c1v_nadam_step(const c1v_nadam_args* a, void* stream) {
+    C1V_REQUIRE(a && a->p && a->g && a->m && a->v && a->sq_partial && a->sched, "nadam_step: null argument");
+    C1V_REQUIRE(a->n > 0 && a->n_partial > 0, "nadam_step: bad size");
+    hipLaunchKernelGGL(nadam_kernel, dim3(grid_for(a->n)), dim3(256), 0, (hipStream_t)stream, *a);
+    C1V_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// EOS truncation + renormalisation (reference :542-565): one wave per sample
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void eos_truncate_kernel(const float* __restrict__ y, int B, int T_len, int V,
+                                                           float* __restrict__ out, int* __restrict__ end_idx) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const float* yb = y + (int64_t)b * T_len * V;
+    float* ob = out + (int64_t)b * T_len * (V - 1);
+    int end = T_len;
+    for (int t = 0; t < T_len; ++t) {
+        // np.argmax: first maximum wins
+        float best = -3.0e38f; int bi = 0x7fffffff;
+        for (int c = lane; c < V; c += 64) { const float v = yb[(int64_t)t * V + c]; if (v > best) { best = v; bi = c; } }
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64);
+            if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+        }
+        if (bi == V - 1) { end = t > 1 ? t : 1; break; }
+    }
+    if (lane == 0 && end_idx) end_idx[b] = end;
+    for (int t = 0; t < T_len; ++t) {
+        if (t < end) {
+            float ss = 0.f;
+            for (int c = lane; c < V - 1; c += 64) { const float v = yb[(int64_t)t * V + c]; ss += v * v; }
+            ss = wave_sum(ss);
+            const float nrm = sqrtf(ss);
+            for (int c = lane; c < V - 1; c += 64) ob[(int64_t)t * (V - 1) + c] = yb[(int64_t)t * V + c] / nrm;
+        } else {
+            for (int c = lane; c < V - 1; c += 64) ob[(int64_t)t * (V - 1) + c] = 0.0f;
+        }
+    }
+}
+extern "C" int c1v_eos_truncate_normalize(const float* y, int32_t B, int32_t T, int32_t V, float* out, int32_t* end_idx, void* stream) {
+    C1V_REQUIRE(y && out, "eos_truncate_normalize: null argument");
+    C1V_REQUIRE(B > 0 && T > 0 && V > 1, "eos_truncate_normalize: bad shape");
+    hipLaunchKernelGGL(eos_truncate_kernel, dim3((unsigned)c1v_cdiv(B, 4)), dim3(256), 0, (hipStream_t)stream, y, B, T, V, out, end_idx);
+    C1V_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Philox4x32-10 counter RNG: element e uses block (e >> 2), word (e & 3); counter = (blk_lo, blk_hi, stream_lo, stream_hi)
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
+        c = make_uint4(hi1 ^ c.y ^ k0, lo1, hi0 ^ c.w ^ k1, lo0);
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return c;
+}
+
+__global__ __launch_bounds__(256) void philox_normal_kernel(float* __restrict__ out, int64_t n, uint64_t seed, uint64_t sid, uint64_t offset,
+                                                            const uint64_t* __restrict__ ctr, uint64_t ctr_mul) {
+    if (ctr) offset += ctr[0] * ctr_mul;
+    const uint64_t first_blk = offset >> 2;
+    const uint64_t last_blk = (offset + n - 1) >> 2;
+    for (uint64_t blk = first_blk + blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; blk <= last_blk; blk += (uint64_t)gridDim.x * blockDim.x) {
+        const uint4 w = philox4x32_10(make_uint4((uint32_t)blk, (uint32_t)(blk >> 32), (uint32_t)sid, (uint32_t)(sid >> 32)), (uint32_t)seed, (uint32_t)(seed >> 32));
+        const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
+        float v[4];
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const float u1 = ((float)(ws[2 * p] >> 8) + 1.0f) * (1.0f / 16777216.0f);
+            const float u2 = (float)(ws[2 * p + 1] >> 8) * (1.0f / 16777216.0f);
+            const float r = sqrtf(-2.0f * logf(u1));
+            const float ang = 6.283185307179586f * u2;
+            v[2 * p] = r * cosf(ang); v[2 * p + 1] = r * sinf(ang);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint64_t e = blk * 4 + k;
+            if (e >= offset && e < offset + (uint64_t)n) out[e - offset] = v[k];
+        }
+    }
+}
+__global__ __launch_bounds__(256) void philox_bernoulli_kernel(uint8_t* __restrict__ out, int64_t n, uint32_t thr, uint64_t seed, uint64_t sid, uint64_t offset,
+                                                               const uint64_t* __restrict__ ctr, uint64_t ctr_mul) {
+    if (ctr) offset += ctr[0] * ctr_mul;
+    const uint64_t first_blk = offset >> 2;
+    const uint64_t last_blk = (offset + n - 1) >> 2;
+    for (uint64_t blk = first_blk + blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; blk <= last_blk; blk += (uint64_t)gridDim.x * blockDim.x) {
+        const uint4 w = philox4x32_10(make_uint4((uint32_t)blk, (uint32_t)(blk >> 32), (uint32_t)sid, (uint32_t)(sid >> 32)), (uint32_t)seed, (uint32_t)(seed >> 32));
+        const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint64_t e = blk * 4 + k;
+            if (e >= offset && e < offset + (uint64_t)n) out[e - offset] = (ws[k] >> 8) < thr ? 1 : 0;
+        }
+    }
+}
+extern "C" int c1v_philox_normal(float* out, int64_t n, uint64_t seed, uint64_t stream_id, uint64_t offset, const uint64_t* ctr, uint64_t ctr_mul, void* stream) {
+    C1V_REQUIRE(out && n > 0, "philox_normal: bad argument");
+    hipLaunchKernelGGL(philox_normal_kernel, dim3(grid_for(n / 4 + 2)), dim3(256), 0, (hipStream_t)stream, out, n, seed, stream_id, offset, ctr, ctr_mul);
+    C1V_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int c1v_philox_bernoulli(uint8_t* out, int64_t n, float keep_prob, uint64_t seed, uint64_t stream_id, uint64_t offset, const uint64_t* ctr, uint64_t ctr_mul, void* stream) {
+    C1V_REQUIRE(out && n > 0 && keep_prob > 0.f && keep_prob <= 1.f, "philox_bernoulli: bad argument");
+    const uint32_t thr = (uint32_t)(keep_prob * 16777216.0f);
+    hipLaunchKernelGGL(philox_bernoulli_kernel, dim3(grid_for(n / 4 + 2)), dim3(256), 0, (hipStream_t)stream, out, n, thr, seed, stream_id, offset, ctr, ctr_mul);
+    C1V_LAUNCH_CHECK();
+    return 0;
+}
+
+// device-side step counter used by captured graphs (RNG offsets advance without host involvement)
+__global__ void counter_add_kernel(uint64_t* ctr, uint64_t inc) { if (threadIdx.x == 0 && blockIdx.x == 0) ctr[0] += inc; }
+extern "C" int c1v_counter_add(uint64_t* ctr, uint64_t inc, void* stream) {
+    C1V_REQUIRE(ctr, "counter_add: null argument");
+    hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, ctr, inc);
+    C1V_LAUNCH_CHECK();
+    return 0;
+}

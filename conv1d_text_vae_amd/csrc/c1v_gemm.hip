@@ -1,0 +1,397 @@
+// MFMA GEMM engine of libc1dvae (gfx950): every GEMM-shaped op of the VAE goes through one of two kernels.
+//
+//   gemm_nt : C[m][n] = sum_k A[m][k] * W[n][k]      conv / deconv / dense forward and dgrad (implicit GEMM:
+//             a conv window over a channels-last buffer IS a contiguous K = k*cp run, so conv = GEMM with
+//             overlapping A rows, lda = cp), with the fused epilogue of c1v_epilogue.
+//   gemm_tn : C[i][j] = sum_r A[r][i] * D[r][j]      wgrad, split over r into fp32 slabs.
+//
+// Both are LDS-tiled, 256 threads = 4 waves (2x2), double-buffered through registers, and are written once
+// for "16 bytes of K per lane": bf16 feeds one v_mfma_f32_16x16x32_bf16 per 16-byte fragment pair, fp32 feeds
+// four v_mfma_f32_16x16x4_f32 (exact fp32 FMA chain) -- the k permutation inside a fragment is the same for
+// both operands, so the sum is unchanged.
+#include "c1v_common.h"
+
+// ------------------------------------------------------------------------------------------------------
+// fused epilogue
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float epi_act_mask(const EpiDev& e, int b, int row, int c) {
+    if (!e.act) return 1.0f;
+    const int64_t idx = (int64_t)b * e.act_bstride + (int64_t)(e.act_off + row * e.act_rowmul) * e.act_cp + c;
+    return load_any(e.act, e.act_dtype, idx) > 0.0f ? e.act_scale : 0.0f;
+}
+__device__ __forceinline__ void epi_store(const EpiDev& e, int b, int row, int c, float v) {
+    const int64_t idx = (int64_t)b * e.dst_bstride + (int64_t)(e.dst_off + row) * e.dst_cp + c;
+    store_any(e.dst, e.dst_dtype, idx, v);
+}
+
+// single-row modes: STORE, UP2, UNPOOL
+__device__ __forceinline__ void epi_row(const EpiDev& e, int m, int n, float v) {
+    if (m >= e.M || n >= e.N) return;
+    const int b = m / e.Le;
+    const int u = m - b * e.Le;
+    if (u >= e.nrows) return;
+    if (e.bias) v += e.bias[n];
+    if (e.relu) v = fmaxf(v, 0.0f);
+    if (e.exp2) v = exp2f(v);
+    int t = u, c = n;
+    if (e.reshape_w > 0) { t = n / e.reshape_w; c = n - t * e.reshape_w; }
+    if (e.row_mode == C1V_ROW_STORE) {
+        if (t >= e.dst_len) return;
+        v *= epi_act_mask(e, b, t, c);
+        if (e.keep) v = e.keep[(int64_t)b * e.sel_bstride + (int64_t)t * e.sel_cp + c] ? v * e.keep_scale : 0.0f;
+        epi_store(e, b, t, c, v);
+    } else if (e.row_mode == C1V_ROW_UP2) {
+        if (2 * t < e.dst_len) epi_store(e, b, 2 * t, c, v);
+        if (2 * t + 1 < e.dst_len) epi_store(e, b, 2 * t + 1, c, v);
+    } else {   // UNPOOL: t indexes the pooled row
+        if (2 * t + 1 >= e.dst_len) return;
+        v *= epi_act_mask(e, b, t, c);
+        const int s = e.sel[(int64_t)b * e.sel_bstride + (int64_t)t * e.sel_cp + c] ? 1 : 0;
+        epi_store(e, b, 2 * t + s, c, v);
+        epi_store(e, b, 2 * t + 1 - s, c, 0.0f);
+    }
+}
+
+// pair modes: POOL2, PAIRSUM.  m0 is even and Le is even, so (m0, m0+1) are rows (u, u+1) of one sample.
+__device__ __forceinline__ void epi_pair(const EpiDev& e, int m0, int n, float v0, float v1) {
+    if (m0 >= e.M || n >= e.N) return;
+    const int b = m0 / e.Le;
+    const int u = m0 - b * e.Le;
+    const int t = u >> 1;
+    if (t >= e.dst_len) return;
+    if (e.bias) { const float bv = e.bias[n]; v0 += bv; v1 += bv; }
+    if (e.relu) { v0 = fmaxf(v0, 0.0f); v1 = fmaxf(v1, 0.0f); }
+    if (e.row_mode == C1V_ROW_POOL2) {
+        if (u + 1 >= e.nrows) return;
+        const int s = v1 > v0 ? 1 : 0;            // first maximum wins ties
+        float v = s ? v1 : v0;
+        const int64_t si = (int64_t)b * e.sel_bstride + (int64_t)t * e.sel_cp + n;
+        if (e.sel) e.sel[si] = (uint8_t)s;
+        if (e.keep) v = e.keep[si] ? v * e.keep_scale : 0.0f;
+        epi_store(e, b, t, n, v);
+    } else {   // PAIRSUM
+        float v = (u < e.nrows ? v0 : 0.0f) + (u + 1 < e.nrows ? v1 : 0.0f);
+        v *= epi_act_mask(e, b, t, n);
+        epi_store(e, b, t, n, v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// fragment MMA: 16 bytes of K per lane
+// ------------------------------------------------------------------------------------------------------
+template <typename T> __device__ __forceinline__ void mma16(f32x4_t& acc, const uint4& a, const uint4& b);
+template <> __device__ __forceinline__ void mma16<bf16_raw>(f32x4_t& acc, const uint4& a, const uint4& b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
+}
+template <> __device__ __forceinline__ void mma16<float>(f32x4_t& acc, const uint4& a, const uint4& b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
+}
+
+// LDS image of an operand tile: 128-byte rows (64 bf16 / 32 fp32 of K), 16-byte chunk index XOR-swizzled with
+// (row>>1)&7 so that the 16 lanes of a ds_read_b128 group (rows r..r+15, one chunk column) hit 16 distinct slots.
+__device__ __forceinline__ int lds_off(int row, int ch) { return row * 128 + ((ch ^ ((row >> 1) & 7)) << 4); }
+
+// ------------------------------------------------------------------------------------------------------
+// NT kernel
+// ------------------------------------------------------------------------------------------------------
+template <typename T, int BM, int BN>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(const NtParams p) {
+    constexpr int WTM = BM / 2, WTN = BN / 2, MI = WTM / 16, NJ = WTN / 16;
+    constexpr int A_IT = BM * 8 / 256, B_IT = BN * 8 / 256;
+    constexpr int STAGE = (BM + BN) * 128;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int lrow = tid >> 3, lch = tid & 7;
+
+    const char* ap[A_IT]; bool av[A_IT];
+    const char* bp[B_IT]; bool bv[B_IT];
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+        const int m = m0 + lrow + i * 32;
+        av[i] = m < p.e.M;
+        const int mm = av[i] ? m : 0;
+        const int b = mm / p.e.Le, u = mm - b * p.e.Le;
+        ap[i] = p.A + (int64_t)b * p.a_bstride_b + (int64_t)(p.a_off + u) * p.lda_b + lch * 16;
+    }
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+        const int n = n0 + lrow + i * 32;
+        bv[i] = n < p.e.N;
+        bp[i] = p.W + (int64_t)(bv[i] ? n : 0) * p.ldw_b + lch * 16;
+    }
+    const int KT = (int)((p.Kb + 127) / 128);
+    uint4 ra[A_IT], rb[B_IT];
+    const uint4 zero4 = make_uint4(0, 0, 0, 0);
+
+    auto gload = [&](int kt) {
+        const int64_t ko = (int64_t)kt * 128;
+        const bool kin = ko + lch * 16 < p.Kb;
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) ra[i] = (av[i] && kin) ? *(const uint4*)(ap[i] + ko) : zero4;
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) rb[i] = (bv[i] && kin) ? *(const uint4*)(bp[i] + ko) : zero4;
+    };
+    auto lstore = [&](int stage) {
+        char* sa = smem + stage * STAGE;
+        char* sb = sa + BM * 128;
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) *(uint4*)(sa + lds_off(lrow + i * 32, lch)) = ra[i];
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) *(uint4*)(sb + lds_off(lrow + i * 32, lch)) = rb[i];
+    };
+
+    f32x4_t acc[MI][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int kt = 0; kt < KT; ++kt) {
+        if (kt + 1 < KT) gload(kt + 1);
+        const char* sa = smem + (kt & 1) * STAGE;
+        const char* sb = sa + BM * 128;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            uint4 af[MI], bf[NJ];
+            const int ch = kk * 4 + (lane >> 4);
+#pragma unroll
+            for (int i = 0; i < MI; ++i) af[i] = *(const uint4*)(sa + lds_off(wm * WTM + i * 16 + (lane & 15), ch));
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) bf[j] = *(const uint4*)(sb + lds_off(wn * WTN + j * 16 + (lane & 15), ch));
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) mma16<T>(acc[i][j], af[i], bf[j]);
+        }
+        if (kt + 1 < KT) lstore((kt + 1) & 1);
+        __syncthreads();
+    }
+
+    // epilogue: acc[i][j][r] is C[m0 + wm*WTM + i*16 + (lane>>4)*4 + r][n0 + wn*WTN + j*16 + (lane&15)]
+    const bool pairs = (p.e.row_mode == C1V_ROW_POOL2) || (p.e.row_mode == C1V_ROW_PAIRSUM);
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int mb = m0 + wm * WTM + i * 16 + (lane >> 4) * 4;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int n = n0 + wn * WTN + j * 16 + (lane & 15);
+            if (pairs) {
+                epi_pair(p.e, mb, n, acc[i][j][0], acc[i][j][1]);
+                epi_pair(p.e, mb + 2, n, acc[i][j][2], acc[i][j][3]);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) epi_row(p.e, mb + r, n, acc[i][j][r]);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// TN kernel (wgrad): 128x128 output tile, K loop over rows r; operands are read "down the columns":
+//   bf16: ds_read_b64_tr_b16 (hardware transpose), fragment element 4w+q <-> row 16w + 4g + q of a 32-row step
+//   fp32: ds_read_b32 straight from the row-major tile (v_mfma_f32_16x16x4_f32 wants one k per lane group)
+// Row pitch = 128*esize + pad (bf16 +32 B, fp32 +64 B) keeps both read patterns conflict-free.
+// ------------------------------------------------------------------------------------------------------
+template <typename T> struct TnCfg;
+template <> struct TnCfg<bf16_raw> { static constexpr int BR = 64, PITCH = 128 * 2 + 32, CHUNKS = 16; };
+template <> struct TnCfg<float>    { static constexpr int BR = 32, PITCH = 128 * 4 + 64, CHUNKS = 32; };
+
+template <typename T>
+__global__ __launch_bounds__(256) void gemm_tn_kernel(const TnParams p) {
+    using Cfg = TnCfg<T>;
+    constexpr int BR = Cfg::BR, PITCH = Cfg::PITCH, CHUNKS = Cfg::CHUNKS;
+    constexpr int ES = sizeof(T);
+    constexpr int IT = BR * CHUNKS / 256;             // 16-byte chunks per thread per operand (= 4)
+    constexpr int TILE = BR * PITCH;
+    constexpr int STAGE = 2 * TILE;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wi = wave >> 1, wj = wave & 1;
+    const int i0 = blockIdx.x * 128, j0 = blockIdx.y * 128;
+    const int tap = blockIdx.z / p.splits, split = blockIdx.z - tap * p.splits;
+    const int64_t rb = p.r_begin + (int64_t)split * p.rows_per_split;
+    int64_t re = rb + p.rows_per_split;
+    if (re > p.r_end) re = p.r_end;
+    const int64_t nrows = re > rb ? re - rb : 0;
+    const int KT = (int)((nrows + BR - 1) / BR);
+
+    const int lrow = tid / CHUNKS, lch = tid % CHUNKS;
+    constexpr int ROWS_PER_IT = 256 / CHUNKS;
+    const bool a_col_ok = (i0 * ES + lch * 16) < p.Ia * ES;
+    const bool d_col_ok = (j0 * ES + lch * 16) < p.Ja * ES;
+    const char* abase = p.A + (int64_t)(p.a_shift0 + tap) * p.lda_b + (int64_t)i0 * ES + lch * 16;
+    const char* dbase = p.D + (int64_t)j0 * ES + lch * 16;
+    uint4 ra[IT], rd[IT];
+    const uint4 zero4 = make_uint4(0, 0, 0, 0);
+
+    auto gload = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < IT; ++i) {
+            const int64_t r = rb + (int64_t)kt * BR + lrow + i * ROWS_PER_IT;
+            const bool ok = r < re;
+            ra[i] = (ok && a_col_ok) ? *(const uint4*)(abase + r * p.lda_b) : zero4;
+            rd[i] = (ok && d_col_ok) ? *(const uint4*)(dbase + r * p.ldd_b) : zero4;
+        }
+    };
+    auto lstore = [&](int stage) {
+        char* sa = smem + stage * STAGE;
+        char* sd = sa + TILE;
+#pragma unroll
+        for (int i = 0; i < IT; ++i) {
+            const int off = (lrow + i * ROWS_PER_IT) * PITCH + lch * 16;
+            *(uint4*)(sa + off) = ra[i];
+            *(uint4*)(sd + off) = rd[i];
+        }
+    };
+
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    if (KT > 0) { gload(0); lstore(0); }
+    __syncthreads();
+    for (int kt = 0; kt < KT; ++kt) {
+        if (kt + 1 < KT) gload(kt + 1);
+        const char* sa = smem + (kt & 1) * STAGE;
+        const char* sd = sa + TILE;
+        if constexpr (sizeof(T) == 2) {
+            const int g = lane >> 4, q = (lane & 15) >> 2, pq = lane & 3;
+#pragma unroll
+            for (int ks = 0; ks < BR / 32; ++ks) {
+                uint4 af[4], df[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int colb = (wi * 64 + i * 16 + 4 * pq) * 2;
+                    const char* a0 = sa + (ks * 32 + 4 * g + q) * PITCH + colb;
+                    s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(C1V_LDS_PTR(s16x4_t, a0));
+                    s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(C1V_LDS_PTR(s16x4_t, a0 + 16 * PITCH));
+                    af[i] = make_uint4(__builtin_bit_cast(uint2, lo).x, __builtin_bit_cast(uint2, lo).y,
+                                       __builtin_bit_cast(uint2, hi).x, __builtin_bit_cast(uint2, hi).y);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int colb = (wj * 64 + j * 16 + 4 * pq) * 2;
+                    const char* d0 = sd + (ks * 32 + 4 * g + q) * PITCH + colb;
+                    s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(C1V_LDS_PTR(s16x4_t, d0));
+                    s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(C1V_LDS_PTR(s16x4_t, d0 + 16 * PITCH));
+                    df[j] = make_uint4(__builtin_bit_cast(uint2, lo).x, __builtin_bit_cast(uint2, lo).y,
+                                       __builtin_bit_cast(uint2, hi).x, __builtin_bit_cast(uint2, hi).y);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) mma16<bf16_raw>(acc[i][j], af[i], df[j]);
+            }
+        } else {
+#pragma unroll 2
+            for (int ks = 0; ks < BR / 4; ++ks) {
+                float af[4], df[4];
+                const int row = ks * 4 + (lane >> 4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) af[i] = *(const float*)(sa + row * PITCH + (wi * 64 + i * 16 + (lane & 15)) * 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) df[j] = *(const float*)(sd + row * PITCH + (wj * 64 + j * 16 + (lane & 15)) * 4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], df[j], acc[i][j], 0, 0, 0);
+            }
+        }
+        if (kt + 1 < KT) lstore((kt + 1) & 1);
+        __syncthreads();
+    }
+
+    const int tap_dst = p.flip ? (p.taps - 1 - tap) : tap;
+    float* out = p.out + (int64_t)split * p.slab_stride + (int64_t)tap_dst * p.tap_stride;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int ii = i0 + wi * 64 + i * 16 + (lane >> 4) * 4 + r;
+            if (ii >= p.I) continue;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int jj = j0 + wj * 64 + j * 16 + (lane & 15);
+                if (jj < p.J) out[(int64_t)ii * p.si + (int64_t)jj * p.sj] = acc[i][j][r];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// host launchers
+// ------------------------------------------------------------------------------------------------------
+template <typename K> static void set_lds(K kern, int bytes) {
+    hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
+
+template <typename T> static int launch_nt_t(const NtParams& p, hipStream_t st) {
+    const int64_t tiles128 = c1v_cdiv(p.e.M, 128) * c1v_cdiv(p.e.N, 128);
+    const bool pairs = p.e.row_mode == C1V_ROW_POOL2 || p.e.row_mode == C1V_ROW_PAIRSUM;
+    C1V_REQUIRE(!pairs || (p.e.Le % 2 == 0), "pair epilogue needs an even row enumeration (Le=%d)", p.e.Le);
+    if (tiles128 >= 192) {
+        static bool once = (set_lds(gemm_nt_kernel<T, 128, 128>, 2 * 256 * 128), true); (void)once;
+        dim3 grid((unsigned)c1v_cdiv(p.e.M, 128), (unsigned)c1v_cdiv(p.e.N, 128));
+        hipLaunchKernelGGL((gemm_nt_kernel<T, 128, 128>), grid, dim3(256), 2 * 256 * 128, st, p);
+    } else {
+        static bool once = (set_lds(gemm_nt_kernel<T, 64, 64>, 2 * 128 * 128), true); (void)once;
+        dim3 grid((unsigned)c1v_cdiv(p.e.M, 64), (unsigned)c1v_cdiv(p.e.N, 64));
+        hipLaunchKernelGGL((gemm_nt_kernel<T, 64, 64>), grid, dim3(256), 2 * 128 * 128, st, p);
+    }
+    C1V_LAUNCH_CHECK();
+    return 0;
+}
+
+int c1v_launch_nt(int dtype, const NtParams& p, hipStream_t st) {
+    C1V_REQUIRE(p.e.M > 0 && p.e.N > 0 && p.Kb > 0, "empty GEMM (M=%d N=%d Kb=%lld)", p.e.M, p.e.N, (long long)p.Kb);
+    C1V_REQUIRE(p.Kb % 16 == 0 && p.lda_b % 16 == 0 && p.ldw_b % 16 == 0 && ((uintptr_t)p.A % 16) == 0 && ((uintptr_t)p.W % 16) == 0,
+                "GEMM operands must be 16-byte aligned (Kb=%lld lda=%lld ldw=%lld)", (long long)p.Kb, (long long)p.lda_b, (long long)p.ldw_b);
+    return dtype == C1V_F32 ? launch_nt_t<float>(p, st) : launch_nt_t<bf16_raw>(p, st);
+}
+
+template <typename T> static int launch_tn_t(const TnParams& p, hipStream_t st) {
+    constexpr int lds = 2 * 2 * TnCfg<T>::BR * TnCfg<T>::PITCH;
+    static bool once = (set_lds(gemm_tn_kernel<T>, lds), true); (void)once;
+    dim3 grid((unsigned)c1v_cdiv(p.I, 128), (unsigned)c1v_cdiv(p.J, 128), (unsigned)(p.taps * p.splits));
+    hipLaunchKernelGGL((gemm_tn_kernel<T>), grid, dim3(256), lds, st, p);
+    C1V_LAUNCH_CHECK();
+    return 0;
+}
+
+int c1v_launch_tn(int dtype, const TnParams& p, hipStream_t st) {
+    C1V_REQUIRE(p.I > 0 && p.J > 0 && p.taps > 0 && p.splits > 0, "empty wgrad");
+    C1V_REQUIRE(p.lda_b % 16 == 0 && p.ldd_b % 16 == 0 && ((uintptr_t)p.A % 16) == 0 && ((uintptr_t)p.D % 16) == 0,
+                "wgrad operands must be 16-byte aligned");
+    return dtype == C1V_F32 ? launch_tn_t<float>(p, st) : launch_tn_t<bf16_raw>(p, st);
+}
+
+int c1v_fill_epi(const c1v_epilogue& e, EpiDev& d, int M, int Le, int nrows, int N) {
+    d.bias = e.bias; d.relu = e.relu; d.row_mode = e.row_mode; d.reshape_w = e.reshape_w; d.exp2 = 0;
+    d.dst = e.dst.data; d.dst_dtype = e.dst.dtype; d.dst_bstride = e.dst.bstride;
+    d.dst_off = e.dst.off; d.dst_len = e.dst.len; d.dst_cp = e.dst.cp; d.dst_c = e.dst.c;
+    d.act = e.act.data; d.act_dtype = e.act.dtype; d.act_bstride = e.act.bstride; d.act_off = e.act.off;
+    d.act_cp = e.act.cp; d.act_rowmul = e.act_rowmul > 0 ? e.act_rowmul : 1; d.act_scale = e.act_scale;
+    d.sel = e.sel; d.sel_bstride = e.sel_bstride; d.sel_cp = e.sel_cp;
+    d.keep = e.keep; d.keep_scale = e.keep_scale;
+    d.M = M; d.Le = Le; d.nrows = nrows; d.N = N;
+    C1V_REQUIRE(e.dst.data != nullptr, "epilogue has no destination");
+    C1V_REQUIRE(e.row_mode >= C1V_ROW_STORE && e.row_mode <= C1V_ROW_UNPOOL, "bad row_mode %d", e.row_mode);
+    C1V_REQUIRE(e.row_mode != C1V_ROW_UNPOOL || e.sel != nullptr, "UNPOOL needs sel");
+    C1V_REQUIRE(e.reshape_w <= 0 || (e.row_mode == C1V_ROW_STORE || e.row_mode == C1V_ROW_UNPOOL), "reshape_w only with STORE/UNPOOL");
+    const int c_max = e.reshape_w > 0 ? e.reshape_w : N;
+    C1V_REQUIRE(c_max <= e.dst.cp, "destination row pitch %d is smaller than %d channels", e.dst.cp, c_max);
+    return 0;
+}

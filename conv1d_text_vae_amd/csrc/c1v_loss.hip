@@ -1,0 +1,536 @@
+// a8 (cosine-softmax cross-entropy vs the vocabulary matrix) and a10-ii (nearest vocabulary row) of libc1dvae.
+//
+// The fused bf16 kernel `vocab_stream_kernel` is the dominant kernel of a training step: per workgroup it keeps
+// 128 rows of the (normalised, pre-scaled) decoder output in registers as MFMA B operands, streams the vocabulary
+// matrix through LDS in 64-row tiles (LDS-DMA, double buffered) and per tile computes
+//     S^T = W_tile . Yhat^T            (v_mfma_f32_32x32x16_bf16, vocabulary row on the accumulator ROW,
+//                                       sample row on the LANE)
+//     E   = exp2(S^T)                  (logits are bounded: |cos| <= 1, tau = 0.1 => no running max needed)
+//     U^T += W_tile^T . E              (the accumulator tile IS the next MFMA's B operand; W^T fragments come from
+//                                       the same LDS image through ds_read_b64_tr_b16)
+// so the [M, N] logits never exist in memory.  Column `ones_col` of W holds 1.0, which makes row `ones_col` of
+// U^T the softmax denominator for free.  Modes: ACCUM (training: U^T), SUMEXP (validation: only the denominator),
+// ARGMAX (predict: fused per-row arg-max, lowest index wins ties).
+#include "c1v_common.h"
+
+// ------------------------------------------------------------------------------------------------------
+// l2 normalise rows: yhat = y * rsqrt(max(sum y^2, 1e-12)) * qscale      (K.l2_normalize, reference :1195)
+// ------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void l2norm_rows_kernel(const float* __restrict__ y, int M, int V, int64_t ldy,
+                                                          T* __restrict__ yhat, int kp, float* __restrict__ rnorm, float qscale) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float* yr = y + (int64_t)row * ldy;
+    float ss = 0.f;
+    for (int c = lane; c < V; c += 64) { const float v = yr[c]; ss += v * v; }
+    ss = wave_sum(ss);
+    const float r = 1.0f / sqrtf(fmaxf(ss, 1e-12f));
+    if (lane == 0 && rnorm) rnorm[row] = r;
+    const float sc = r * qscale;
+    for (int c = lane; c < kp; c += 64) ElemTraits<T>::store(yhat, (int64_t)row * kp + c, c < V ? yr[c] * sc : 0.0f);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// fused vocabulary stream kernel (bf16)
+// ------------------------------------------------------------------------------------------------------
+enum { VS_ACCUM = 0, VS_SUMEXP = 1, VS_ARGMAX = 2 };
+constexpr int VS_BN = 64;     // vocabulary rows per LDS tile
+constexpr int VS_BM = 128;    // sample rows per workgroup (4 waves x 32)
+
+template <int CB> struct VsCfg {
+    static constexpr int KP = CB * 32;
+    static constexpr int ROWB = KP * 2;                                  // data bytes per row
+    static constexpr int PITCH = ROWB + ((CB % 2 == 0) ? 64 : 128);      // == 64 or 192 (mod 256)
+    static constexpr int CPR = PITCH / 16;                               // physical 16-byte chunks per row
+    static constexpr int DCH = ROWB / 16;                                // data chunks per row
+    static constexpr int STAGE = VS_BN * PITCH;
+    static constexpr int PIECES = STAGE / 1024;                          // 1 KiB LDS-DMA pieces per tile
+    static constexpr int PPW = (PIECES + 3) / 4;                         // pieces per wave
+    static_assert(STAGE % 1024 == 0, "tile must be whole LDS-DMA pieces");
+    static_assert(PITCH % 256 == 64 || PITCH % 256 == 192, "pitch keeps the transposed reads conflict-free");
+};
+
+// byte offset of 16-byte chunk `ch` of row r inside a tile image (chunk index XOR-swizzled in its low 2 bits)
+template <int CB> __device__ __forceinline__ int vs_off(int r, int ch) { return r * VsCfg<CB>::PITCH + ((ch ^ ((r >> 2) & 3)) << 4); }
+
+template <int CB, int MODE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void vocab_stream_kernel(const bf16_raw* __restrict__ yhat, int M, const bf16_raw* __restrict__ w, int N, int n_base,
+                         int tiles_total, int tiles_per_split, float* __restrict__ ut, int m_pad, int ones_col,
+                         float* __restrict__ part_score, int* __restrict__ part_idx) {
+    using Cfg = VsCfg<CB>;
+    constexpr int KS = CB * 2;                     // 16-wide k steps of GEMM1
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int split = blockIdx.y;
+    const int m_row = blockIdx.x * VS_BM + wave * 32 + l31;
+    const int t_begin = split * tiles_per_split;
+    int t_end = t_begin + tiles_per_split;
+    if (t_end > tiles_total) t_end = tiles_total;
+
+    // LDS-DMA source offsets of this lane for the pieces of its wave (bytes from the tile's first row)
+    int src_off[Cfg::PPW];
+#pragma unroll
+    for (int i = 0; i < Cfg::PPW; ++i) {
+        const int piece = wave + 4 * i;
+        const int L = piece * 64 + lane;
+        const int r = L / Cfg::CPR, chp = L - r * Cfg::CPR;
+        const int ch = chp ^ ((r >> 2) & 3);
+        src_off[i] = (piece < Cfg::PIECES && chp < Cfg::DCH) ? r * Cfg::ROWB + ch * 16 : 0;
+    }
+    auto stage_tile = [&](int t, int stage) {
+        const char* tile = (const char*)w + (int64_t)t * VS_BN * Cfg::ROWB;
+#pragma unroll
+        for (int i = 0; i < Cfg::PPW; ++i) {
+            const int piece = wave + 4 * i;
+            if (piece < Cfg::PIECES)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(tile + src_off[i]),
+                                                 C1V_LDS_PTR(void, smem + stage * Cfg::STAGE + piece * 1024), 16, 0, 0);
+        }
+    };
+
+    if (t_begin < t_end) stage_tile(t_begin, 0);
+
+    // this wave's 32 sample rows as MFMA B operands: B[k = 8h + j][col = l31] = yhat[m_row][16 s + 8h + j]
+    bf16x8_t yf[KS];
+    {
+        const uint4* yp = (const uint4*)(yhat + (int64_t)(m_row < M ? m_row : 0) * Cfg::KP) + h;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            uint4 v = (m_row < M) ? yp[2 * s] : make_uint4(0, 0, 0, 0);
+            yf[s] = __builtin_bit_cast(bf16x8_t, v);
+        }
+    }
+
+    f32x16_t U[MODE == VS_ACCUM ? CB : 1];
+#pragma unroll
+    for (int c = 0; c < (MODE == VS_ACCUM ? CB : 1); ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) U[c][r] = 0.f;
+    float sumexp = 0.f;
+    float best = -3.0e38f;
+    int best_idx = 0x7fffffff;
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    for (int t = t_begin; t < t_end; ++t) {
+        const int stage = (t - t_begin) & 1;
+        if (t + 1 < t_end) stage_tile(t + 1, stage ^ 1);
+        const char* sw = smem + stage * Cfg::STAGE;
+        const int n0 = t * VS_BN;
+
+        // GEMM1: S[nb][reg] = logit of vocabulary row n0 + nb*32 + (reg&3) + 8*(reg>>2) + 4h, sample row m_row
+        f32x16_t S[2];
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) S[nb][r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const uint4 a = *(const uint4*)(sw + vs_off<CB>(nb * 32 + l31, 2 * s + h));
+                S[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), yf[s], S[nb], 0, 0, 0);
+            }
+        }
+
+        if constexpr (MODE == VS_ARGMAX) {
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int n = n0 + nb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const float v = S[nb][r];
+                    if (n < N && v > best) { best = v; best_idx = n; }
+                }
+        } else {
+            const bool tail = n0 + VS_BN > N;
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float e = __builtin_amdgcn_exp2f(S[nb][r]);
+                    if (tail) { const int n = n0 + nb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h; if (n >= N) e = 0.f; }
+                    S[nb][r] = e;
+                }
+            if constexpr (MODE == VS_SUMEXP) {
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sumexp += S[nb][r];
+            } else {
+                // GEMM2: U^T[c][m] += sum_n W[n][c] * E[n][m]; k slot (h, j) of step (nb, ks) is vocabulary row
+                // nb*32 + 16ks + 8(j>>2) + 4h + (j&3): exactly the accumulator rows held in regs 8ks..8ks+7.
+                bf16x8_t pf[2][2];
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) pf[nb][ks][j] = (__bf16)S[nb][8 * ks + j];
+                const int q = (lane & 15) >> 2, pq = lane & 3, cg = (lane >> 4) & 1;
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb) {
+                    const int chunk = cb * 4 + 2 * cg + (pq >> 1);
+                    const int sub = 8 * (pq & 1);
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                        for (int ks = 0; ks < 2; ++ks) {
+                            const int r0 = nb * 32 + 16 * ks + 4 * h + q;
+                            s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(C1V_LDS_PTR(s16x4_t, sw + vs_off<CB>(r0, chunk) + sub));
+                            s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(C1V_LDS_PTR(s16x4_t, sw + vs_off<CB>(r0 + 8, chunk) + sub));
+                            const uint4 a = make_uint4(__builtin_bit_cast(uint2, lo).x, __builtin_bit_cast(uint2, lo).y,
+                                                       __builtin_bit_cast(uint2, hi).x, __builtin_bit_cast(uint2, hi).y);
+                            U[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), pf[nb][ks], U[cb], 0, 0, 0);
+                        }
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    const int m_out = blockIdx.x * VS_BM + wave * 32 + l31;
+    if constexpr (MODE == VS_ACCUM) {
+        float* o = ut + (int64_t)split * Cfg::KP * m_pad + m_out;
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int c = cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                o[(int64_t)c * m_pad] = U[cb][r];
+            }
+    } else if constexpr (MODE == VS_SUMEXP) {
+        sumexp += __shfl_xor(sumexp, 32, 64);
+        if (h == 0) ut[((int64_t)split * Cfg::KP + ones_col) * m_pad + m_out] = sumexp;
+    } else {
+        const float ob = __shfl_xor(best, 32, 64);
+        const int oi = __shfl_xor(best_idx, 32, 64);
+        if (ob > best || (ob == best && oi < best_idx)) { best = ob; best_idx = oi; }
+        if (h == 0) {
+            part_score[(int64_t)split * m_pad + m_out] = best;
+            part_idx[(int64_t)split * m_pad + m_out] = best_idx == 0x7fffffff ? 0x7fffffff : best_idx + n_base;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// finish: per sample row  p_t, clip, xent, d loss / d y      (reference :1198-1203 + Keras batch mean)
+// ------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void xent_finish_kernel(const float* __restrict__ ut, int splits, int kp, int m_pad, int ones_col,
+                                                          const T* __restrict__ yhat, const T* __restrict__ w,
+                                                          const float* __restrict__ rnorm, float qscale,
+                                                          const int* __restrict__ ids, int B, int T_len, int V, int B_global,
+                                                          float* __restrict__ xent_rows, c1v_seq dy) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* u = (float*)smem;                       // [32][kp + 1]
+    const int up = kp + 1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int M = B * T_len;
+    const int m0 = blockIdx.x * 32;
+    {   // phase 1: sum the split slabs, transposing [c][m] -> u[m][c]
+        const int ml = tid & 31, cg = tid >> 5;
+        const bool need_all = dy.data != nullptr;
+        for (int c = cg; c < kp; c += 8) {
+            float s = 0.f;
+            if (need_all || c == ones_col)
+                for (int sp = 0; sp < splits; ++sp) s += ut[((int64_t)sp * kp + c) * m_pad + m0 + ml];
+            u[ml * up + c] = s;
+        }
+    }
+    __syncthreads();
+    const float inv_q = 1.0f / qscale;
+    const float inv_tau_eff = qscale * 0.6931471805599453f;     // 1/tau = qscale * ln 2
+    for (int rr = 0; rr < 8; ++rr) {
+        const int ml = wave * 8 + rr;
+        const int m = m0 + ml;
+        if (m >= M) break;
+        const int b = m / T_len, t = m - b * T_len;
+        const int id = ids[m];
+        const float* ur = u + ml * up;
+        const float sumexp = ur[ones_col];
+        float cnt = 0.f;
+        for (int tt = lane; tt < T_len; tt += 64) cnt += ids[b * T_len + tt] >= 0 ? 1.f : 0.f;
+        cnt = wave_sum(cnt);
+        float st = 0.f;
+        if (id >= 0)
+            for (int c = lane; c < V; c += 64)
+                st += ElemTraits<T>::load(yhat, (int64_t)m * kp + c) * ElemTraits<T>::load(w, (int64_t)id * kp + c);
+        st = wave_sum(st);
+        float p_t = exp2f(st) / sumexp;
+        const bool mask = id >= 0;
+        const bool live = mask && p_t > 1e-7f && p_t < (1.0f - 1e-7f);
+        const float p_c = fminf(fmaxf(p_t, 1e-7f), 1.0f - 1e-7f);
+        if (lane == 0) xent_rows[m] = mask ? -logf(p_c) : 0.0f;
+        if (dy.data == nullptr) continue;
+        const float coef = live ? inv_tau_eff / (cnt * (float)B_global) : 0.0f;
+        const float inv_se = 1.0f / sumexp;
+        float dot = 0.f;
+        for (int c = lane; c < V; c += 64) {
+            const float wt = id >= 0 ? ElemTraits<T>::load(w, (int64_t)id * kp + c) : 0.f;
+            const float dyh = coef * (ur[c] * inv_se - wt);
+            dot += dyh * ElemTraits<T>::load(yhat, (int64_t)m * kp + c) * inv_q;
+        }
+        dot = wave_sum(dot);
+        const float rn = rnorm[m];
+        const bool normal = rn < 0.99e6f;                       // sum y^2 >= 1e-12
+        for (int c = lane; c < V; c += 64) {
+            const float wt = id >= 0 ? ElemTraits<T>::load(w, (int64_t)id * kp + c) : 0.f;
+            const float dyh = coef * (ur[c] * inv_se - wt);
+            const float yh = ElemTraits<T>::load(yhat, (int64_t)m * kp + c) * inv_q;
+            const float g = normal ? (dyh - yh * dot) * rn : dyh * rn;
+            store_any(dy.data, dy.dtype, (int64_t)b * dy.bstride + (int64_t)(dy.off + t) * dy.cp + c, g);
+        }
+    }
+}
+
+// loss scalars (single block, deterministic order)
+__global__ __launch_bounds__(256) void loss_reduce_kernel(const float* __restrict__ xent_rows, const int* __restrict__ ids,
+                                                          const float* __restrict__ kl_b, int B, int T_len, int B_global,
+                                                          float* __restrict__ out3, float* __restrict__ xent_b) {
+    __shared__ float sx[256], sk[256];
+    float ax = 0.f, ak = 0.f;
+    for (int b = threadIdx.x; b < B; b += 256) {
+        float s = 0.f, c = 0.f;
+        for (int t = 0; t < T_len; ++t) { s += xent_rows[b * T_len + t]; c += ids[b * T_len + t] >= 0 ? 1.f : 0.f; }
+        const float xb = s / c;
+        if (xent_b) xent_b[b] = xb;
+        ax += xb;
+        ak += kl_b ? kl_b[b] : 0.f;
+    }
+    sx[threadIdx.x] = ax; sk[threadIdx.x] = ak;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) { sx[threadIdx.x] += sx[threadIdx.x + o]; sk[threadIdx.x] += sk[threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float inv = 1.0f / (float)B_global;
+        out3[0] = (sx[0] - sk[0]) * inv; out3[1] = sx[0] * inv; out3[2] = sk[0] * inv;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// arg-max helpers
+// ------------------------------------------------------------------------------------------------------
+// merge R partial (score, idx) rows: highest score, ties -> lowest index
+__global__ void argmax_merge_kernel(const float* __restrict__ sc, const int* __restrict__ ix, int R, int64_t stride, int M,
+                                    float* __restrict__ score, int* __restrict__ idx) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    float best = sc[m]; int bi = ix[m];
+    for (int r = 1; r < R; ++r) {
+        const float v = sc[(int64_t)r * stride + m]; const int i = ix[(int64_t)r * stride + m];
+        if (v > best || (v == best && i < bi)) { best = v; bi = i; }
+    }
+    score[m] = best; idx[m] = bi;
+}
+
+// fp32 path: arg-max over a chunk of materialised logits [M][ld], merged into running (score, idx)
+__global__ __launch_bounds__(256) void row_argmax_kernel(const float* __restrict__ logits, int M, int64_t ld, int n_count, int n_first,
+                                                         float* __restrict__ score, int* __restrict__ idx, int first_chunk) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    float best = -3.0e38f; int bi = 0x7fffffff;
+    for (int n = lane; n < n_count; n += 64) {
+        const float v = logits[(int64_t)row * ld + n];
+        if (v > best) { best = v; bi = n + n_first; }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64);
+        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    if (lane == 0) {
+        if (!first_chunk) { const float pv = score[row]; const int pi = idx[row]; if (pv > best || (pv == best && pi < bi)) { best = pv; bi = pi; } }
+        score[row] = best; idx[row] = bi;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// host entry points
+// ------------------------------------------------------------------------------------------------------
+extern "C" int c1v_l2norm_rows(const c1v_l2norm_args* a, void* stream) {
+    C1V_REQUIRE(a && a->y && a->yhat, "l2norm: null argument");
+    C1V_REQUIRE(a->M > 0 && a->V > 0 && a->kp >= a->V, "l2norm: bad shape M=%d V=%d kp=%d", a->M, a->V, a->kp);
+    dim3 grid((unsigned)c1v_cdiv(a->M, 4));
+    if (a->dtype == C1V_F32)
+        hipLaunchKernelGGL(l2norm_rows_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, a->y, a->M, a->V, a->ldy, (float*)a->yhat, a->kp, a->rnorm, a->qscale);
+    else
+        hipLaunchKernelGGL(l2norm_rows_kernel<bf16_raw>, grid, dim3(256), 0, (hipStream_t)stream, a->y, a->M, a->V, a->ldy, (bf16_raw*)a->yhat, a->kp, a->rnorm, a->qscale);
+    C1V_LAUNCH_CHECK();
+    return 0;
+}
+
+template <int CB, int MODE>
+static int launch_vs(const bf16_raw* yhat, int M, const bf16_raw* w, int N, int n_base, int splits, float* ut, int m_pad, int ones_col,
+                     float* ps, int* pi, hipStream_t st) {
+    using Cfg = VsCfg<CB>;
+    static bool once = (hipFuncSetAttribute((const void*)vocab_stream_kernel<CB, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * Cfg::STAGE), true);
+    (void)once;
+    const int tiles_total = (int)c1v_cdiv(N, VS_BN);
+    const int tps = (int)c1v_cdiv(tiles_total, splits);
+    dim3 grid((unsigned)(m_pad / VS_BM), (unsigned)splits);
+    hipLaunchKernelGGL((vocab_stream_kernel<CB, MODE>), grid, dim3(256), 2 * Cfg::STAGE, st, yhat, M, w, N, n_base, tiles_total, tps, ut, m_pad, ones_col, ps, pi);
+    C1V_LAUNCH_CHECK();
+    return 0;
+}
+
+template <int MODE>
+static int dispatch_vs(int kp, const bf16_raw* yhat, int M, const bf16_raw* w, int N, int n_base, int splits, float* ut, int m_pad, int ones_col,
+                       float* ps, int* pi, hipStream_t st) {
+    switch (kp) {
+        case 32:  return launch_vs<1, MODE>(yhat, M, w, N, n_base, splits, ut, m_pad, ones_col, ps, pi, st);
+        case 64:  return launch_vs<2, MODE>(yhat, M, w, N, n_base, splits, ut, m_pad, ones_col, ps, pi, st);
+        case 320: return launch_vs<10, MODE>(yhat, M, w, N, n_base, splits, ut, m_pad, ones_col, ps, pi, st);
+        default: return 1;   // no fused instantiation for this width
+    }
+}
+
+__global__ void zero_f32_kernel(float* p, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = 0.f;
+}
+
+// unfused path (fp32, and bf16 widths without a fused instantiation): NT GEMM (+exp2) into `logits`, TN GEMM out.
+static int xent_accum_unfused(const c1v_xent_accum_args* a, hipStream_t st) {
+    C1V_REQUIRE(a->logits && a->n_chunk > 0, "cos_softmax_accum: this dtype/width needs the `logits` scratch");
+    const int es = c1v_esize(a->dtype);
+    const int chunks = (int)c1v_cdiv(a->N, a->n_chunk);
+    C1V_REQUIRE(a->splits % chunks == 0, "cos_softmax_accum: splits (%d) must be a multiple of the chunk count (%d)", a->splits, chunks);
+    const int spc = a->splits / chunks;
+    for (int ch = 0; ch < chunks; ++ch) {
+        const int nc0 = ch * a->n_chunk;
+        const int ncount = (a->N - nc0) < a->n_chunk ? (a->N - nc0) : a->n_chunk;
+        // E[n][m] = exp2(sum_k W[nc0+n][k] * yhat[m][k])     stored in the compute dtype [n_chunk][m_pad]
+        NtParams p{};
+        p.A = (const char*)a->w + (int64_t)nc0 * a->kp * es; p.a_bstride_b = (int64_t)a->kp * es; p.lda_b = (int64_t)a->kp * es; p.a_off = 0;
+        p.W = (const char*)a->yhat; p.ldw_b = (int64_t)a->kp * es; p.Kb = (int64_t)a->kp * es;
+        EpiDev& e = p.e;
+        e = EpiDev{};
+        e.exp2 = 1; e.row_mode = C1V_ROW_STORE;
+        e.dst = a->logits; e.dst_dtype = a->dtype; e.dst_bstride = a->m_pad; e.dst_off = 0; e.dst_len = 1; e.dst_cp = a->m_pad; e.dst_c = a->M;
+        e.act_rowmul = 1; e.M = ncount; e.Le = 1; e.nrows = 1; e.N = a->M;
+        int rc = c1v_launch_nt(a->dtype, p, st);
+        if (rc) return rc;
+        if (!a->need_u) {
+            // only the denominator: column sums of E over n  == row `ones_col` of U^T
+            TnParams t{};
+            t.A = (const char*)a->w + (int64_t)nc0 * a->kp * es + (int64_t)(a->ones_col / 128 * 128) * es; t.lda_b = (int64_t)a->kp * es;
+            t.I = a->ones_col % 128 + 1; t.Ia = (a->kp - a->ones_col / 128 * 128) < 128 ? (a->kp - a->ones_col / 128 * 128) : 128;
+            t.D = (const char*)a->logits; t.ldd_b = (int64_t)a->m_pad * es; t.J = a->M; t.Ja = a->m_pad;
+            t.r_begin = 0; t.r_end = ncount; t.rows_per_split = c1v_cdiv(ncount, spc);
+            t.a_shift0 = 0; t.taps = 1; t.flip = 0; t.tap_stride = 0; t.si = a->m_pad; t.sj = 1;
+            t.out = a->ut + ((int64_t)ch * spc * a->kp + (a->ones_col / 128 * 128)) * a->m_pad; t.slab_stride = (int64_t)a->kp * a->m_pad; t.splits = spc;
+            rc = c1v_launch_tn(a->dtype, t, st);
+        } else {
+            TnParams t{};
+            t.A = (const char*)a->w + (int64_t)nc0 * a->kp * es; t.lda_b = (int64_t)a->kp * es; t.I = a->kp; t.Ia = a->kp;
+            t.D = (const char*)a->logits; t.ldd_b = (int64_t)a->m_pad * es; t.J = a->M; t.Ja = a->m_pad;
+            t.r_begin = 0; t.r_end = ncount; t.rows_per_split = c1v_cdiv(ncount, spc);
+            t.a_shift0 = 0; t.taps = 1; t.flip = 0; t.tap_stride = 0; t.si = a->m_pad; t.sj = 1;
+            t.out = a->ut + (int64_t)ch * spc * a->kp * a->m_pad; t.slab_stride = (int64_t)a->kp * a->m_pad; t.splits = spc;
+            rc = c1v_launch_tn(a->dtype, t, st);
+        }
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+extern "C" int c1v_cos_softmax_accum(const c1v_xent_accum_args* a, void* stream) {
+    C1V_REQUIRE(a && a->yhat && a->w && a->ut, "cos_softmax_accum: null argument");
+    C1V_REQUIRE(a->M > 0 && a->N > 0 && a->kp % 32 == 0 && a->splits > 0, "cos_softmax_accum: bad shape M=%d N=%d kp=%d splits=%d", a->M, a->N, a->kp, a->splits);
+    C1V_REQUIRE(a->m_pad % VS_BM == 0 && a->m_pad >= a->M, "cos_softmax_accum: m_pad (%d) must be a multiple of %d covering M", a->m_pad, VS_BM);
+    C1V_REQUIRE(a->n_pad % VS_BN == 0 && a->n_pad >= a->N, "cos_softmax_accum: n_pad (%d) must be a multiple of %d covering N", a->n_pad, VS_BN);
+    C1V_REQUIRE(a->ones_col >= 0 && a->ones_col < a->kp, "cos_softmax_accum: ones_col out of range");
+    hipStream_t st = (hipStream_t)stream;
+    if (a->dtype == C1V_BF16) {
+        int rc = a->need_u
+            ? dispatch_vs<VS_ACCUM>(a->kp, (const bf16_raw*)a->yhat, a->M, (const bf16_raw*)a->w, a->N, 0, a->splits, a->ut, a->m_pad, a->ones_col, nullptr, nullptr, st)
+            : dispatch_vs<VS_SUMEXP>(a->kp, (const bf16_raw*)a->yhat, a->M, (const bf16_raw*)a->w, a->N, 0, a->splits, a->ut, a->m_pad, a->ones_col, nullptr, nullptr, st);
+        if (rc <= 0) return rc;
+    }
+    return xent_accum_unfused(a, st);
+}
+extern "C" int c1v_cos_softmax_xent_fwd(const c1v_xent_accum_args* a, void* stream) {
+    C1V_REQUIRE(a, "null argument");
+    c1v_xent_accum_args b = *a; b.need_u = 0; return c1v_cos_softmax_accum(&b, stream);
+}
+extern "C" int c1v_cos_softmax_xent_bwd(const c1v_xent_accum_args* a, void* stream) {
+    C1V_REQUIRE(a, "null argument");
+    c1v_xent_accum_args b = *a; b.need_u = 1; return c1v_cos_softmax_accum(&b, stream);
+}
+
+extern "C" int c1v_cos_softmax_finish(const c1v_xent_finish_args* a, void* stream) {
+    C1V_REQUIRE(a && a->ut && a->yhat && a->w && a->ids && a->xent_rows && a->rnorm, "cos_softmax_finish: null argument");
+    C1V_REQUIRE(a->B > 0 && a->T > 0 && a->V > 0 && a->V <= a->kp && a->splits > 0, "cos_softmax_finish: bad shape");
+    C1V_REQUIRE(a->m_pad >= (int)(c1v_cdiv((int64_t)a->B * a->T, 32) * 32), "cos_softmax_finish: m_pad too small");
+    C1V_REQUIRE(a->dy.data == nullptr || (a->dy.cp >= a->V && a->dy.len >= a->T), "cos_softmax_finish: dy buffer too small");
+    const int M = a->B * a->T;
+    const size_t lds = (size_t)32 * (a->kp + 1) * sizeof(float);
+    dim3 grid((unsigned)c1v_cdiv(M, 32));
+    if (a->dtype == C1V_F32)
+        hipLaunchKernelGGL(xent_finish_kernel<float>, grid, dim3(256), lds, (hipStream_t)stream, a->ut, a->splits, a->kp, a->m_pad, a->ones_col,
+                           (const float*)a->yhat, (const float*)a->w, a->rnorm, a->qscale, a->ids, a->B, a->T, a->V, a->B_global, a->xent_rows, a->dy);
+    else
+        hipLaunchKernelGGL(xent_finish_kernel<bf16_raw>, grid, dim3(256), lds, (hipStream_t)stream, a->ut, a->splits, a->kp, a->m_pad, a->ones_col,
+                           (const bf16_raw*)a->yhat, (const bf16_raw*)a->w, a->rnorm, a->qscale, a->ids, a->B, a->T, a->V, a->B_global, a->xent_rows, a->dy);
+    C1V_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int c1v_loss_reduce(const float* xent_rows, const int32_t* ids, const float* kl_b, int32_t B, int32_t T, int32_t B_global,
+                               float* out3, float* xent_b, void* stream) {
+    C1V_REQUIRE(xent_rows && ids && out3 && B > 0 && T > 0 && B_global > 0, "loss_reduce: bad argument");
+    hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, xent_rows, ids, kl_b, B, T, B_global, out3, xent_b);
+    C1V_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int c1v_argmax_merge(const float* scores, const int32_t* idxs, int32_t R, int32_t M, float* score, int32_t* idx, void* stream) {
+    C1V_REQUIRE(scores && idxs && score && idx && R > 0 && M > 0, "argmax_merge: bad argument");
+    hipLaunchKernelGGL(argmax_merge_kernel, dim3((unsigned)c1v_cdiv(M, 256)), dim3(256), 0, (hipStream_t)stream, scores, idxs, R, (int64_t)M, M, score, idx);
+    C1V_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int c1v_vocab_argmax(const c1v_vocab_argmax_args* a, void* stream) {
+    C1V_REQUIRE(a && a->q && a->w && a->score && a->idx, "vocab_argmax: null argument");
+    C1V_REQUIRE(a->M > 0 && a->N > 0 && a->kp % 32 == 0, "vocab_argmax: bad shape M=%d N=%d kp=%d", a->M, a->N, a->kp);
+    hipStream_t st = (hipStream_t)stream;
+    if (a->dtype == C1V_BF16 && a->part_score && a->part_idx && a->splits > 0 && a->m_pad % VS_BM == 0 && a->m_pad >= a->M &&
+        a->n_pad % VS_BN == 0 && a->n_pad >= a->N) {
+        int rc = dispatch_vs<VS_ARGMAX>(a->kp, (const bf16_raw*)a->q, a->M, (const bf16_raw*)a->w, a->N, a->n_base, a->splits, nullptr, a->m_pad, 0,
+                                        a->part_score, a->part_idx, st);
+        if (rc < 0) return rc;
+        if (rc == 0) {
+            hipLaunchKernelGGL(argmax_merge_kernel, dim3((unsigned)c1v_cdiv(a->M, 256)), dim3(256), 0, st, a->part_score, a->part_idx, a->splits,
+                               (int64_t)a->m_pad, a->M, a->score, a->idx);
+            C1V_LAUNCH_CHECK();
+            return 0;
+        }
+    }
+    // unfused: logits[m][n] per chunk of vocabulary rows, then row arg-max
+    C1V_REQUIRE(a->logits && a->n_chunk > 0, "vocab_argmax: this dtype/width needs the `logits` scratch");
+    const int es = c1v_esize(a->dtype);
+    const int chunks = (int)c1v_cdiv(a->N, a->n_chunk);
+    for (int ch = 0; ch < chunks; ++ch) {
+        const int nc0 = ch * a->n_chunk;
+        const int ncount = (a->N - nc0) < a->n_chunk ? (a->N - nc0) : a->n_chunk;
+        NtParams p{};
+        p.A = (const char*)a->q; p.a_bstride_b = (int64_t)a->kp * es; p.lda_b = (int64_t)a->kp * es; p.a_off = 0;
+        p.W = (const char*)a->w + (int64_t)nc0 * a->kp * es; p.ldw_b = (int64_t)a->kp * es; p.Kb = (int64_t)a->kp * es;
+        p.e = EpiDev{};
+        p.e.row_mode = C1V_ROW_STORE; p.e.dst = a->logits; p.e.dst_dtype = C1V_F32; p.e.dst_bstride = a->n_chunk; p.e.dst_off = 0; p.e.dst_len = 1;
+        p.e.dst_cp = a->n_chunk; p.e.dst_c = ncount; p.e.act_rowmul = 1; p.e.M = a->M; p.e.Le = 1; p.e.nrows = 1; p.e.N = ncount;
+        int rc = c1v_launch_nt(a->dtype, p, st);
+        if (rc) return rc;
+        hipLaunchKernelGGL(row_argmax_kernel, dim3((unsigned)c1v_cdiv(a->M, 4)), dim3(256), 0, st, a->logits, a->M, (int64_t)a->n_chunk, ncount,
+                           nc0 + a->n_base, a->score, a->idx, ch == 0 ? 1 : 0);
+        C1V_LAUNCH_CHECK();
+    }
+    return 0;
+}

@@ -1,0 +1,736 @@
+"""Device engine of the Conv1D text VAE: owns every HBM buffer and sequences the libc1dvae kernels.
+
+This is the MI355X replacement for what the reference obtains from Keras' `Model.fit_generator` /
+`predict_on_batch` on the graphs built by `__create_model` (conv1d_text_vae.py:1185-1343): one forward, the
+cosine-softmax loss, backward, global-norm clip and Nadam update per call of `train_step`, captured once into a
+HIP graph and replayed.  PyTorch is used for allocation, streams, graph capture and `torch.distributed` only.
+
+HBM layout (T = compute dtype, bf16 or fp32):
+  * activations are channels-last "sequence buffers" [batch*pitch + slack, cp]: per-sample row pitch `pitch`
+    (even), valid rows [off, off+len), channel pitch cp = roundup(C, 32); padding rows/channels stay zero, which
+    is what implements 'same'/'full' convolution padding and lets wgrad run over the flat row index.
+  * every conv layer owns an input buffer X and an output-gradient buffer dO with the same pitch.
+  * parameters: one flat fp32 buffer (Keras layouts), plus flat grad / Nadam m / v buffers; per-layer operand
+    copies in T ([n_out][k*cp], K-major) are refreshed by one `pack_weights` launch after each update.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from .geometry import Geometry, init_keras_weights, merge_heads, split_heads
+
+KEEP_PROB = 0.7          # Dropout(0.3) :1243, :1254
+TAU = 0.1                # :1319
+CLIPNORM = 10.0          # :1329
+NADAM_LR = 0.002         # Keras Nadam default (the estimator's `lr` is not used for the VAE, :1329)
+LOG2E = 1.4426950408889634
+
+
+def _pad(n: int, m: int) -> int:
+    return (n + m - 1) // m * m
+
+
+def _even(n: int) -> int:
+    return n + (n & 1)
+
+
+class Buf:
+    """torch tensor + c1v_seq descriptor."""
+
+    def __init__(self, t: torch.Tensor, batch: int, bstride: int, off: int, length: int, cp: int, c: int):
+        self.t = t
+        self.batch, self.bstride, self.off, self.len, self.cp, self.c = batch, bstride, off, length, cp, c
+        self.code = L.F32 if t.dtype == torch.float32 else L.BF16
+
+    def seq(self, off: Optional[int] = None, length: Optional[int] = None) -> L.Seq:
+        return L.Seq(self.t.data_ptr(), self.code, self.batch, self.bstride, self.off if off is None else off,
+                     self.len if length is None else length, self.cp, self.c)
+
+    @property
+    def pitch(self) -> int:
+        return self.bstride // self.cp
+
+    def valid(self) -> torch.Tensor:
+        """[batch, len, c] view of the valid region (testing / export)."""
+        rows = self.t[: self.batch * self.pitch].view(self.batch, self.pitch, self.cp)
+        return rows[:, self.off:self.off + self.len, :self.c]
+
+
+def _null_seq() -> L.Seq:
+    return L.Seq(None, 0, 0, 0, 0, 0, 0, 0)
+
+
+class VAEEngine:
+    def __init__(self, geom: Geometry, batch: int, vocab_vectors: Optional[np.ndarray] = None, dtype: str = 'bf16',
+                 device: str = 'cuda:0', seed: int = 0, world_size: int = 1, rank: int = 0,
+                 frozen_encoder: bool = False, weights: Optional[Dict[str, np.ndarray]] = None,
+                 std_scale: float = 1.0):
+        if not torch.cuda.is_available():
+            raise L.C1VError('VAEEngine needs a GPU: the HIP kernels are the only implementation of this path.')
+        self.lib = L.load()
+        self.g = geom
+        self.B = int(batch)
+        self.world, self.rank = int(world_size), int(rank)
+        self.Bg = self.B * self.world
+        self.dev = torch.device(device)
+        self.tdt = torch.bfloat16 if dtype == 'bf16' else torch.float32
+        if dtype not in ('bf16', 'f32'):
+            raise ValueError('dtype must be bf16 or f32')
+        self.code = L.BF16 if dtype == 'bf16' else L.F32
+        self.frozen = bool(frozen_encoder)
+        self.seed = int(seed)
+        self.std_scale = float(std_scale)
+        self._keep = []        # python objects that must outlive the captured graphs
+        self._graphs: Dict[str, torch.cuda.CUDAGraph] = {}
+        k = geom.kernel_size
+        B = self.B
+        nl = len(geom.n_filters)
+
+        # ---------------- parameters
+        self.seg_names = [n for n, _ in geom.segments()]
+        self.seg_shapes = dict(geom.segments())
+        self.seg_off: Dict[str, int] = {}
+        o = 0
+        for n, s in geom.segments():
+            self.seg_off[n] = o
+            o += _pad(int(np.prod(s)), 4)             # 16-byte aligned segments
+        self.P = o
+        z = lambda *shape, dt=torch.float32: torch.zeros(*shape, dtype=dt, device=self.dev)
+        self.params = z(self.P)
+        self.grads = z(self.P)
+        self.nadam_m = z(self.P)
+        self.nadam_v = z(self.P)
+        self.nadam_state = torch.tensor([0.0, 1.0, NADAM_LR], dtype=torch.float64, device=self.dev)
+        self.sched = z(8)
+        self.norm_out = z(1)
+        self.step_ctr = torch.zeros(1, dtype=torch.int64, device=self.dev)
+        self.set_weights(weights if weights is not None else init_keras_weights(geom, seed))
+
+        # ---------------- activation buffers
+        def seqbuf(batch, pitch, off, length, c, dt=None):
+            cp = _pad(c, 32)
+            t = z((batch * pitch + L.SLACK_ROWS) * cp, dt=dt or self.tdt)
+            return Buf(t, batch, pitch * cp, off, length, cp, c)
+
+        self.x_in = z(B, geom.input_text_size, geom.input_vector_size)        # featuriser output (fp32)
+        self.ids_in = torch.full((B, geom.output_text_size), -1, dtype=torch.int32, device=self.dev)
+        self.Xe: List[Buf] = []
+        self.dOe: List[Buf] = []
+        self.sel: List[torch.Tensor] = []
+        c_in = geom.input_vector_size
+        for l in range(nl):
+            Lin = geom.enc_in_len[l]
+            pitch = _even(Lin + k - 1)
+            self.Xe.append(seqbuf(B, pitch, 0, Lin, c_in))
+            self.dOe.append(seqbuf(B, pitch, k - 1, geom.enc_len_conv[l], geom.n_filters[l]))
+            self.sel.append(z(B, geom.enc_len_pool[l], geom.n_filters[l], dt=torch.uint8))
+            c_in = geom.n_filters[l]
+        F_last = geom.n_filters[-1]
+        self.flat = geom.flat_size
+        self.flat_p = _pad(self.flat, 32)
+        self.H = Buf(z(B * self.flat_p + 64, dt=self.tdt), B, self.flat_p, 0, geom.enc_len_pool[-1], F_last, F_last)
+        D = geom.latent_dim
+        self.D = D
+        self.Dp = _pad(D, 32)
+        self.D2p = _pad(2 * D, 32)
+        self.mlv = z(B, 2 * D)
+        self.eps = z(B, D)
+        self.eps_zero = z(B, D)
+        self.keep_e = torch.ones(B, self.flat, dtype=torch.uint8, device=self.dev)
+        self.keep_d = torch.ones(B, D, dtype=torch.uint8, device=self.dev)
+        self.zd = z(B * self.Dp + 64, dt=self.tdt)
+        self.z_out = z(B, D)
+        self.kl_b = z(B)
+        self.dzd = z(B, D)
+        self.dmlv = z(B * self.D2p + 64, dt=self.tdt)
+        nd = geom.n_times * geom.width
+        self.nd = nd
+        self.nd_p = _pad(nd, 32)
+        self.dDense = Buf(z(B * self.nd_p + 64, dt=self.tdt), B, self.nd_p, 0, geom.n_times, geom.width, geom.width)
+        self.Xd: List[Buf] = []
+        self.dOd: List[Buf] = []
+        c_in = geom.width
+        for i, f in enumerate(geom.dec_filters):
+            Lin = geom.dec_in_len[i]
+            pitch = _even(Lin + 3 * (k - 1))
+            self.Xd.append(seqbuf(B, pitch, k - 1, Lin, c_in))
+            self.dOd.append(seqbuf(B, pitch, k - 1, geom.dec_len_deconv[i], f))
+            c_in = f
+        To = geom.output_text_size
+        self.V = geom.output_vector_size
+        pitch = _even(To + 2 * (k - 1))
+        self.Xf = seqbuf(B, pitch, geom.pad_left, To, c_in)
+        self.dOf = seqbuf(B, pitch, k - 1, To, self.V)
+        self.Y = Buf(z(B * To * self.V + 64), B, To * self.V, 0, To, self.V, self.V)
+        self.post = z(B, To, self.V - 1)
+        self.end_idx = torch.zeros(B, dtype=torch.int32, device=self.dev)
+
+        # ---------------- loss
+        self.M = B * To
+        self.m_pad = _pad(self.M, 128)
+        self.kp = _pad(self.V + 1, 32)               # at least one spare column: `ones_col` carries the softmax denominator
+        self.ones_col = self.V
+        self.qscale = LOG2E / TAU
+        self.yhat = z(self.m_pad * self.kp, dt=self.tdt)
+        self.rnorm = z(self.m_pad)
+        self.xent_rows = z(self.m_pad)
+        self.xent_b = z(B)
+        self.loss_out = z(3)
+        self.N = 0
+        self.set_vocab(vocab_vectors)
+
+        # ---------------- operand copies of the weights + gradient slabs
+        self._build_weight_ops()
+        self._build_ops()
+
+    # ------------------------------------------------------------------------------------------------------
+    # weights
+    # ------------------------------------------------------------------------------------------------------
+    def set_weights(self, keras_weights: Dict[str, np.ndarray]):
+        w = merge_heads(keras_weights) if 'z_mean/kernel' in keras_weights else keras_weights
+        host = np.zeros(self.P, dtype=np.float32)
+        for n in self.seg_names:
+            a = np.asarray(w[n], dtype=np.float32)
+            if tuple(a.shape) != tuple(self.seg_shapes[n]):
+                raise ValueError('weight `{0}` has shape {1}, expected {2}'.format(n, a.shape, self.seg_shapes[n]))
+            host[self.seg_off[n]:self.seg_off[n] + a.size] = a.reshape(-1)
+        self.params.copy_(torch.from_numpy(host))
+        if hasattr(self, '_pack_all'):
+            self._pack_all()
+
+    def get_weights(self) -> Dict[str, np.ndarray]:
+        host = self.params.detach().cpu().numpy()
+        w = {n: host[self.seg_off[n]:self.seg_off[n] + int(np.prod(self.seg_shapes[n]))].reshape(self.seg_shapes[n]).copy()
+             for n in self.seg_names}
+        return split_heads(w)
+
+    def get_grads(self) -> Dict[str, np.ndarray]:
+        host = self.grads.detach().cpu().numpy()
+        w = {n: host[self.seg_off[n]:self.seg_off[n] + int(np.prod(self.seg_shapes[n]))].reshape(self.seg_shapes[n]).copy()
+             for n in self.seg_names}
+        return split_heads(w)
+
+    def reset_optimizer(self, lr: float = NADAM_LR):
+        self.nadam_m.zero_()
+        self.nadam_v.zero_()
+        self.nadam_state.copy_(torch.tensor([0.0, 1.0, lr], dtype=torch.float64))
+
+    def set_lr(self, lr: float):
+        self.nadam_state[2] = lr
+
+    def get_lr(self) -> float:
+        return float(self.nadam_state[2].item())
+
+    def set_vocab(self, vocab_vectors: Optional[np.ndarray]):
+        """W = `output_word_vectors` [N, V_out] (unit rows; reference :1326 uses its transpose as a constant)."""
+        if vocab_vectors is None:
+            self.N = 0
+            return
+        W = np.asarray(vocab_vectors, dtype=np.float32)
+        if W.ndim != 2 or W.shape[1] != self.V:
+            raise ValueError('vocabulary matrix must be [N, {0}]'.format(self.V))
+        self.N = W.shape[0]
+        self.n_pad = _pad(self.N, 64)
+        host = np.zeros((self.n_pad, self.kp), dtype=np.float32)
+        host[:self.N, :self.V] = W
+        host[:self.N, self.ones_col] = 1.0
+        self.w_vocab = torch.from_numpy(host).to(self.dev).to(self.tdt).contiguous()
+        fused = self.code == L.BF16 and self.kp in (32, 64, 320)
+        tiles = self.n_pad // 64
+        if fused:
+            want = max(1, (2 * 256) // max(1, self.m_pad // 128))
+            self.x_splits = max(1, min(tiles, want, 16))
+            self.n_chunk = 0
+            self.logits = None
+        else:
+            self.n_chunk = int(min(self.n_pad, max(1024, (1 << 28) // self.m_pad)))
+            chunks = (self.N + self.n_chunk - 1) // self.n_chunk
+            spc = 8 if self.n_chunk >= 2048 else 1
+            self.x_splits = chunks * spc
+            self.logits = torch.zeros(self.n_chunk * self.m_pad, dtype=self.tdt, device=self.dev)
+        self.ut = torch.zeros(self.x_splits * self.kp * self.m_pad, dtype=torch.float32, device=self.dev)
+        if hasattr(self, '_ops_built'):
+            self._build_ops()
+
+    # ------------------------------------------------------------------------------------------------------
+    # operand copies + wgrad slabs
+    # ------------------------------------------------------------------------------------------------------
+    def _pslice(self, name: str) -> int:
+        return self.params.data_ptr() + 4 * self.seg_off[name]
+
+    def _build_weight_ops(self):
+        g, k = self.g, self.g.kernel_size
+        descs: List[L.PackDesc] = []
+        self.wop: Dict[str, torch.Tensor] = {}
+
+        def add(key, src_name, n_count, taps, c_count, cp, flip, s_tap, s_c, s_n):
+            ldk = taps * cp
+            t = torch.zeros(n_count * ldk + 64, dtype=self.tdt, device=self.dev)
+            self.wop[key] = t
+            descs.append(L.PackDesc(self._pslice(src_name), t.data_ptr(), self.code, n_count, taps, c_count, cp, flip,
+                                    ldk, s_tap, s_c, s_n))
+
+        c_in = g.input_vector_size
+        for l, f in enumerate(g.n_filters):
+            name = 'encoder_conv1d_%d/kernel' % (l + 1)            # (k, C, F)
+            add('enc%d_fwd' % l, name, f, k, c_in, _pad(c_in, 32), 0, c_in * f, f, 1)
+            if l > 0:
+                add('enc%d_dg' % l, name, c_in, k, f, _pad(f, 32), 1, c_in * f, 1, f)
+            c_in = f
+        D2 = 2 * self.D
+        add('heads_fwd', 'z_heads/kernel', D2, 1, self.flat, self.flat_p, 0, 0, D2, 1)       # (flat, 2D)
+        add('heads_dg', 'z_heads/kernel', self.flat, 1, D2, self.D2p, 0, 0, 1, D2)
+        add('dense_fwd', 'deconv_decoder_dense/kernel', self.nd, 1, self.D, self.Dp, 0, 0, self.nd, 1)   # (D, nd)
+        add('dense_dg', 'deconv_decoder_dense/kernel', self.D, 1, self.nd, self.nd_p, 0, 0, 1, self.nd)
+        c_in = g.width
+        for i, f in enumerate(g.dec_filters):
+            name = 'deconv_decoder_%d_deconv1d_part2/kernel' % (i + 1)      # (k, 1, F, C)
+            add('dec%d_fwd' % i, name, f, k, c_in, _pad(c_in, 32), 1, f * c_in, 1, c_in)
+            add('dec%d_dg' % i, name, c_in, k, f, _pad(f, 32), 0, f * c_in, c_in, 1)
+            c_in = f
+        name = 'deconv_decoder_embeddings/kernel'                           # (k, C, V)
+        add('out_fwd', name, self.V, k, c_in, _pad(c_in, 32), 0, c_in * self.V, self.V, 1)
+        add('out_dg', name, c_in, k, self.V, _pad(self.V, 32), 1, c_in * self.V, 1, self.V)
+
+        arr = (L.PackDesc * len(descs))(*descs)
+        self.pack_descs = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.dev)
+        self.n_pack = len(descs)
+        self.pack_max = max(d.n_count * d.taps * d.c_count for d in descs)
+
+        def pack_all():
+            L.call('c1v_pack_weights', self.pack_descs.data_ptr(), self.n_pack, self.pack_max, self._stream())
+        self._pack_all = pack_all
+        pack_all()
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
+
+    # ------------------------------------------------------------------------------------------------------
+    # op construction
+    # ------------------------------------------------------------------------------------------------------
+    def _epi(self, dst: L.Seq, row_mode=L.ROW_STORE, bias=None, relu=0, reshape_w=0, act: Optional[L.Seq] = None,
+             act_rowmul=1, act_scale=1.0, sel=None, sel_bstride=0, sel_cp=0, keep=None, keep_scale=1.0) -> L.Epilogue:
+        return L.Epilogue(bias, relu, row_mode, reshape_w, dst, act if act is not None else _null_seq(), act_rowmul,
+                          act_scale, sel, sel_bstride, sel_cp, keep, keep_scale)
+
+    def _bias_ptr(self, name: str) -> int:
+        return self._pslice(name)
+
+    def _op(self, fn: str, args):
+        self._keep.append(args)
+        f = getattr(self.lib, fn)
+        ref = C.byref(args)
+
+        def run():
+            rc = f(ref, self._stream())
+            if rc != 0:
+                L.check(rc, fn)
+        return run
+
+    def _build_ops(self):
+        g, k, B = self.g, self.g.kernel_size, self.B
+        nl = len(g.n_filters)
+        nd = len(g.dec_filters)
+        self._keep = []
+        self._graphs = {}
+        op = self._op
+        # ---- encoder forward (train / inference differ only in the dropout mask of the last layer)
+        self.ops_pack_in = [op('c1v_pack_input', L.PackInputArgs(self.x_in.data_ptr(), g.input_text_size,
+                                                                  g.input_vector_size, self.Xe[0].seq()))]
+
+        def enc_fwd(train: bool):
+            ops = []
+            for l in range(nl):
+                last = l == nl - 1
+                F = g.n_filters[l]
+                dstb = self.H if last else self.Xe[l + 1]
+                dst = dstb.seq(length=g.enc_len_pool[l])
+                keep = self.keep_e.data_ptr() if (train and last) else None
+                e = self._epi(dst, L.ROW_POOL2, self._bias_ptr('encoder_conv1d_%d/bias' % (l + 1)), 1,
+                              sel=self.sel[l].data_ptr(), sel_bstride=g.enc_len_pool[l] * F, sel_cp=F,
+                              keep=keep, keep_scale=1.0 / KEEP_PROB)
+                ops.append(op('c1v_conv1d_fwd', L.ConvArgs(self.Xe[l].seq(), 0, g.enc_len_conv[l], k,
+                                                           self.wop['enc%d_fwd' % l].data_ptr(), F, e)))
+            mlv_seq = L.Seq(self.mlv.data_ptr(), L.F32, B, 2 * self.D, 0, 1, 2 * self.D, 2 * self.D)
+            e = self._epi(mlv_seq, L.ROW_STORE, self._bias_ptr('z_heads/bias'))
+            ops.append(op('c1v_dense_fwd', L.DenseArgs(self.H.t.data_ptr(), self.code, B, self.flat_p, self.flat_p,
+                                                       self.wop['heads_fwd'].data_ptr(), self.flat_p, 2 * self.D, e)))
+            return ops
+
+        def latent(train: bool, sample: bool):
+            a = L.LatentArgs(self.mlv.data_ptr(), B, self.D, (self.eps if sample else self.eps_zero).data_ptr(),
+                             self.keep_d.data_ptr() if train else None, KEEP_PROB, self.std_scale if sample else 0.0,
+                             self.zd.data_ptr(), self.code, self.Dp, self.z_out.data_ptr(), self.kl_b.data_ptr(),
+                             self.dzd.data_ptr(), self.Bg, self.dmlv.data_ptr(), self.D2p)
+            return a
+
+        self._lat_train = latent(True, True)
+        self._lat_eval = latent(False, True)
+        self._lat_infer = latent(False, False)
+
+        def dec_fwd():
+            ops = []
+            e = self._epi(self.Xd[0].seq(), L.ROW_STORE, self._bias_ptr('deconv_decoder_dense/bias'), 1, reshape_w=g.width)
+            ops.append(op('c1v_dense_fwd', L.DenseArgs(self.zd.data_ptr(), self.code, B, self.Dp, self.Dp,
+                                                       self.wop['dense_fwd'].data_ptr(), self.Dp, self.nd, e)))
+            for i in range(nd):
+                last = i == nd - 1
+                dstb = self.Xf if last else self.Xd[i + 1]
+                dst_len = g.output_text_size if last else 2 * g.dec_len_deconv[i]
+                e = self._epi(dstb.seq(length=dst_len), L.ROW_UP2,
+                              self._bias_ptr('deconv_decoder_%d_deconv1d_part2/bias' % (i + 1)), 1)
+                ops.append(op('c1v_deconv1d_fwd', L.ConvArgs(self.Xd[i].seq(), 0, g.dec_len_deconv[i], k,
+                                                             self.wop['dec%d_fwd' % i].data_ptr(), g.dec_filters[i], e)))
+            e = self._epi(self.Y.seq(), L.ROW_STORE, self._bias_ptr('deconv_decoder_embeddings/bias'))
+            ops.append(op('c1v_conv1d_fwd', L.ConvArgs(self.Xf.seq(), 0, g.output_text_size, k,
+                                                       self.wop['out_fwd'].data_ptr(), self.V, e)))
+            return ops
+
+        self.ops_enc_train = enc_fwd(True)
+        self.ops_enc_infer = enc_fwd(False)
+        self.ops_lat_train = [op('c1v_latent_head_fwd', self._lat_train)]
+        self.ops_lat_eval = [op('c1v_latent_head_fwd', self._lat_eval)]
+        self.ops_lat_infer = [op('c1v_latent_head_fwd', self._lat_infer)]
+        self.ops_dec = dec_fwd()
+        self.ops_post = []
+        f_eos = self.lib.c1v_eos_truncate_normalize
+
+        def run_post():
+            L.check(f_eos(self.Y.t.data_ptr(), B, g.output_text_size, self.V, self.post.data_ptr(),
+                          self.end_idx.data_ptr(), self._stream()), 'c1v_eos_truncate_normalize')
+        self.ops_post = [run_post]
+        self._ops_built = True
+        if self.N == 0:
+            return
+
+        # ---- loss
+        def loss_ops(train: bool):
+            ops = [op('c1v_l2norm_rows', L.L2NormArgs(self.Y.t.data_ptr(), self.M, self.V, self.V, self.yhat.data_ptr(),
+                                                      self.code, self.kp, self.rnorm.data_ptr(), self.qscale))]
+            ops.append(op('c1v_cos_softmax_accum', L.XentAccumArgs(
+                self.yhat.data_ptr(), self.code, self.M, self.kp, self.w_vocab.data_ptr(), self.N, self.n_pad,
+                self.ut.data_ptr(), self.m_pad, self.x_splits, 1 if train else 0, self.ones_col,
+                self.logits.data_ptr() if self.logits is not None else None, self.n_chunk)))
+            ops.append(op('c1v_cos_softmax_finish', L.XentFinishArgs(
+                self.ut.data_ptr(), self.x_splits, self.kp, self.m_pad, self.ones_col, self.yhat.data_ptr(),
+                self.w_vocab.data_ptr(), self.code, self.rnorm.data_ptr(), self.qscale, self.ids_in.data_ptr(), B,
+                g.output_text_size, self.V, self.Bg, self.xent_rows.data_ptr(), self.xent_b.data_ptr(),
+                self.dOf.seq() if train else _null_seq())))
+            f_red = self.lib.c1v_loss_reduce
+
+            def red():
+                L.check(f_red(self.xent_rows.data_ptr(), self.ids_in.data_ptr(), self.kl_b.data_ptr(), B,
+                              g.output_text_size, self.Bg, self.loss_out.data_ptr(), self.xent_b.data_ptr(),
+                              self._stream()), 'c1v_loss_reduce')
+            ops.append(red)
+            return ops
+
+        self.ops_loss_train = loss_ops(True)
+        self.ops_loss_eval = loss_ops(False)
+
+        # ---- backward
+        segs: List[L.SegDesc] = []
+        self.slabs: Dict[str, torch.Tensor] = {}
+
+        def slab(name: str, splits: int, frozen=False):
+            count = int(np.prod(self.seg_shapes[name]))
+            t = torch.zeros(splits * count, dtype=torch.float32, device=self.dev)
+            self.slabs[name] = t
+            segs.append(L.SegDesc(t.data_ptr(), count, splits, 1, 0, self.seg_off[name], count, 1 if frozen else 0, 0))
+            return t
+
+        def row_splits(rows: int) -> int:
+            return int(max(1, min(32, rows // 512)))
+
+        def conv_wgrad(X: Buf, dO: Buf, wname: str, bname: str, C_in: int, F: int, flip: int, tap_stride, si, sj, frozen=False):
+            rows = B * X.pitch
+            sp = row_splits(rows)
+            wt = slab(wname, sp, frozen)
+            bt = slab(bname, sp, frozen)
+            count = int(np.prod(self.seg_shapes[wname]))
+            ops = []
+            if not frozen:
+                ops.append(op('c1v_conv1d_wgrad', L.WgradArgs(X.t.data_ptr(), X.cp, C_in, dO.t.data_ptr(), dO.cp, F,
+                                                              self.code, k - 1, rows, -(k - 1), k, flip, tap_stride, si, sj,
+                                                              wt.data_ptr(), count, sp)))
+                ops.append(op('c1v_colsum', L.ColsumArgs(dO.t.data_ptr(), self.code, rows, dO.cp, F, bt.data_ptr(), F, sp)))
+            return ops
+
+        def dense_wgrad(a_ptr, lda, I, d_ptr, ldd, J, wname, bname, frozen=False):
+            wt = slab(wname, 1, frozen)
+            bt = slab(bname, 1, frozen)
+            ops = []
+            if not frozen:
+                ops.append(op('c1v_dense_wgrad', L.WgradArgs(a_ptr, lda, I, d_ptr, ldd, J, self.code, 0, B, 0, 1, 0, 0, J, 1,
+                                                             wt.data_ptr(), I * J, 1)))
+                ops.append(op('c1v_colsum', L.ColsumArgs(d_ptr, self.code, B, ldd, J, bt.data_ptr(), J, 1)))
+            return ops
+
+        bwd = []
+        # segments must be registered in flat-buffer order for readability only; order of ops is the backward order
+        C_last = g.dec_filters[-1]
+        bwd += conv_wgrad(self.Xf, self.dOf, 'deconv_decoder_embeddings/kernel', 'deconv_decoder_embeddings/bias',
+                          C_last, self.V, 0, C_last * self.V, self.V, 1)
+        e = self._epi(self.dOd[nd - 1].seq(), L.ROW_PAIRSUM, act=self.Xf.seq(), act_rowmul=2, act_scale=1.0)
+        bwd.append(op('c1v_conv1d_dgrad', L.ConvArgs(self.dOf.seq(), g.pad_left, g.output_text_size, k,
+                                                     self.wop['out_dg'].data_ptr(), C_last, e)))
+        for i in reversed(range(nd)):
+            C_in = g.width if i == 0 else g.dec_filters[i - 1]
+            F = g.dec_filters[i]
+            nm = 'deconv_decoder_%d_deconv1d_part2' % (i + 1)
+            bwd += conv_wgrad(self.Xd[i], self.dOd[i], nm + '/kernel', nm + '/bias', C_in, F, 1, F * C_in, 1, C_in)
+            if i > 0:
+                e = self._epi(self.dOd[i - 1].seq(), L.ROW_PAIRSUM, act=self.Xd[i].seq(), act_rowmul=2, act_scale=1.0)
+            else:
+                e = self._epi(self.dDense.seq(), L.ROW_STORE, act=self.Xd[0].seq(), act_rowmul=1, act_scale=1.0)
+            bwd.append(op('c1v_deconv1d_dgrad', L.ConvArgs(self.dOd[i].seq(), k - 1, g.dec_in_len[i], k,
+                                                           self.wop['dec%d_dg' % i].data_ptr(), C_in, e)))
+        bwd += dense_wgrad(self.zd.data_ptr(), self.Dp, self.D, self.dDense.t.data_ptr(), self.nd_p, self.nd,
+                           'deconv_decoder_dense/kernel', 'deconv_decoder_dense/bias')
+        if not self.frozen:
+            dzd_seq = L.Seq(self.dzd.data_ptr(), L.F32, B, self.D, 0, 1, self.D, self.D)
+            bwd.append(op('c1v_dense_dgrad', L.DenseArgs(self.dDense.t.data_ptr(), self.code, B, self.nd_p, self.nd_p,
+                                                         self.wop['dense_dg'].data_ptr(), self.nd_p, self.D,
+                                                         self._epi(dzd_seq))))
+            bwd.append(op('c1v_latent_head_bwd', self._lat_train))
+        bwd += dense_wgrad(self.H.t.data_ptr(), self.flat_p, self.flat, self.dmlv.data_ptr(), self.D2p, 2 * self.D,
+                           'z_heads/kernel', 'z_heads/bias', self.frozen)
+        if not self.frozen:
+            F = g.n_filters[-1]
+            e = self._epi(self.dOe[nl - 1].seq(), L.ROW_UNPOOL, reshape_w=F, act=self.H.seq(), act_scale=1.0 / KEEP_PROB,
+                          sel=self.sel[nl - 1].data_ptr(), sel_bstride=g.enc_len_pool[nl - 1] * F, sel_cp=F)
+            bwd.append(op('c1v_dense_dgrad', L.DenseArgs(self.dmlv.data_ptr(), self.code, B, self.D2p, self.D2p,
+                                                         self.wop['heads_dg'].data_ptr(), self.D2p, self.flat, e)))
+        for l in reversed(range(nl)):
+            C_in = g.input_vector_size if l == 0 else g.n_filters[l - 1]
+            F = g.n_filters[l]
+            nm = 'encoder_conv1d_%d' % (l + 1)
+            bwd += conv_wgrad(self.Xe[l], self.dOe[l], nm + '/kernel', nm + '/bias', C_in, F, 0, C_in * F, F, 1, self.frozen)
+            if l > 0 and not self.frozen:
+                Fp = g.n_filters[l - 1]
+                e = self._epi(self.dOe[l - 1].seq(), L.ROW_UNPOOL, act=self.Xe[l].seq(), act_scale=1.0,
+                              sel=self.sel[l - 1].data_ptr(), sel_bstride=g.enc_len_pool[l - 1] * Fp, sel_cp=Fp)
+                bwd.append(op('c1v_conv1d_dgrad', L.ConvArgs(self.dOe[l].seq(), 0, g.enc_in_len[l], k,
+                                                             self.wop['enc%d_dg' % l].data_ptr(), Fp, e)))
+        self.ops_bwd = bwd
+
+        # ---- optimizer
+        arr = (L.SegDesc * len(segs))(*segs)
+        self.seg_descs = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.dev)
+        self.n_seg = len(segs)
+        self.seg_max = max(s.count for s in segs)
+        self.n_partial = int(self.lib.c1v_grad_finalize_partials(self.n_seg, self.seg_max))
+        self.sq_partial = torch.zeros(max(self.n_partial, 256), dtype=torch.float32, device=self.dev)
+        f_fin = self.lib.c1v_grad_finalize
+        f_sq = self.lib.c1v_sqnorm_partial
+        f_adv = self.lib.c1v_nadam_advance
+
+        def finalize():
+            L.check(f_fin(self.seg_descs.data_ptr(), self.n_seg, self.seg_max, self.grads.data_ptr(),
+                          self.sq_partial.data_ptr(), self.n_partial, self._stream()), 'c1v_grad_finalize')
+
+        def sqnorm():
+            L.check(f_sq(self.grads.data_ptr(), self.P, self.sq_partial.data_ptr(), 256, self._stream()), 'c1v_sqnorm_partial')
+
+        def advance():
+            L.check(f_adv(self.nadam_state.data_ptr(), self.sched.data_ptr(), self._stream()), 'c1v_nadam_advance')
+
+        self.ops_finalize = [finalize]
+        nad = L.NadamArgs(self.params.data_ptr(), self.grads.data_ptr(), self.nadam_m.data_ptr(), self.nadam_v.data_ptr(),
+                          self.P, self.sq_partial.data_ptr(), self.n_partial if self.world == 1 else 256,
+                          1.0, CLIPNORM, self.sched.data_ptr(), 0.9, 0.999, 1e-7, self.norm_out.data_ptr())
+        self.ops_update = ([] if self.world == 1 else [sqnorm]) + [advance, op('c1v_nadam_step', nad), self._pack_all]
+
+        # ---- RNG (device counter => replayable)
+        f_n = self.lib.c1v_philox_normal
+        f_b = self.lib.c1v_philox_bernoulli
+        f_c = self.lib.c1v_counter_add
+
+        def rng():
+            st = self._stream()
+            ctr = self.step_ctr.data_ptr()
+            L.check(f_n(self.eps.data_ptr(), B * self.D, self.seed, 1, self.rank * B * self.D, ctr, self.Bg * self.D, st), 'philox')
+            L.check(f_b(self.keep_e.data_ptr(), B * self.flat, KEEP_PROB, self.seed, 2, self.rank * B * self.flat, ctr,
+                        self.Bg * self.flat, st), 'philox')
+            L.check(f_b(self.keep_d.data_ptr(), B * self.D, KEEP_PROB, self.seed, 3, self.rank * B * self.D, ctr,
+                        self.Bg * self.D, st), 'philox')
+            L.check(f_c(ctr, 1, st), 'counter_add')
+
+        def rng_eval():
+            st = self._stream()
+            ctr = self.step_ctr.data_ptr()
+            L.check(f_n(self.eps.data_ptr(), B * self.D, self.seed, 4, self.rank * B * self.D, ctr, self.Bg * self.D, st), 'philox')
+            L.check(f_c(ctr, 1, st), 'counter_add')
+        self.ops_rng = [rng]
+        self.ops_rng_eval = [rng_eval]
+
+    # ------------------------------------------------------------------------------------------------------
+    # execution
+    # ------------------------------------------------------------------------------------------------------
+    @staticmethod
+    def _run(ops):
+        for o in ops:
+            o()
+
+    def _graph(self, key: str, ops):
+        """Run `ops` through a HIP graph captured on first use (eager warm-up first so that one-time kernel
+        attribute calls happen outside the capture)."""
+        gr = self._graphs.get(key)
+        if gr is None:
+            torch.cuda.synchronize(self.dev)
+            saved = self._save_state()
+            s = torch.cuda.Stream(self.dev)
+            s.wait_stream(torch.cuda.current_stream(self.dev))
+            with torch.cuda.stream(s):
+                self._run(ops)
+            torch.cuda.current_stream(self.dev).wait_stream(s)
+            torch.cuda.synchronize(self.dev)
+            self._restore_state(saved)
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr):
+                self._run(ops)
+            self._restore_state(saved)
+            self._graphs[key] = gr
+        gr.replay()
+
+    def _save_state(self):
+        return [t.clone() for t in (self.params, self.nadam_m, self.nadam_v, self.nadam_state, self.step_ctr)]
+
+    def _restore_state(self, saved):
+        for t, s in zip((self.params, self.nadam_m, self.nadam_v, self.nadam_state, self.step_ctr), saved):
+            t.copy_(s)
+        self._pack_all()
+
+    def load_batch(self, x: Optional[np.ndarray] = None, ids: Optional[np.ndarray] = None):
+        if x is not None:
+            self.x_in.copy_(torch.as_tensor(x, dtype=torch.float32), non_blocking=True)
+        if ids is not None:
+            self.ids_in.copy_(torch.as_tensor(ids, dtype=torch.int32), non_blocking=True)
+
+    def train_ops(self, with_rng: bool):
+        ops = (self.ops_rng if with_rng else []) + self.ops_pack_in + self.ops_enc_train + self.ops_lat_train + \
+            self.ops_dec + self.ops_loss_train + self.ops_bwd + self.ops_finalize
+        return ops
+
+    def train_step(self, use_graph: bool = True, fixed_rng: bool = False, all_reduce=None):
+        """One fit step on the batch resident in x_in / ids_in: forward, loss, backward, clip, Nadam, operand refresh.
+        fixed_rng: eps / keep_e / keep_d were filled by the caller (parity runs)."""
+        if self.N == 0:
+            raise L.C1VError('train_step needs the vocabulary matrix (set_vocab)')
+        if self.world == 1:
+            ops = self.train_ops(not fixed_rng) + self.ops_update
+            if use_graph:
+                self._graph('train_fixed' if fixed_rng else 'train', ops)
+            else:
+                self._run(ops)
+        else:
+            a, b = self.train_ops(not fixed_rng), self.ops_update
+            if use_graph:
+                self._graph('train_a_fixed' if fixed_rng else 'train_a', a)
+            else:
+                self._run(a)
+            all_reduce(self.grads)                      # RCCL sum over ranks; loss terms carry 1/B_global already
+            if use_graph:
+                self._graph('train_b', b)
+            else:
+                self._run(b)
+
+    def eval_step(self, use_graph: bool = True, fixed_rng: bool = False):
+        """Validation loss of the resident batch (dropout off, eps still sampled -- Keras test phase of FullVAE)."""
+        ops = ([] if fixed_rng else self.ops_rng_eval) + self.ops_pack_in + self.ops_enc_infer + self.ops_lat_eval + \
+            self.ops_dec + self.ops_loss_eval
+        if use_graph:
+            self._graph('eval_fixed' if fixed_rng else 'eval', ops)
+        else:
+            self._run(ops)
+
+    def loss(self) -> float:
+        return float(self.loss_out[0].item())
+
+    def encode(self, use_graph: bool = True) -> torch.Tensor:
+        """vae_encoder_.predict_on_batch (:404): z_mean of the resident batch, [B, latent] fp32 (device)."""
+        ops = self.ops_pack_in + self.ops_enc_infer
+        if use_graph:
+            self._graph('encode', ops)
+        else:
+            self._run(ops)
+        return self.mlv[:, :self.D]
+
+    def reconstruct(self, use_graph: bool = True, postprocess: bool = True) -> torch.Tensor:
+        """vae_decoder_(vae_encoder_(x)) (:440) and, optionally, postprocess_reconstructed_word_vectors (:439)."""
+        ops = self.ops_pack_in + self.ops_enc_infer + self.ops_lat_infer + self.ops_dec + (self.ops_post if postprocess else [])
+        if use_graph:
+            self._graph('recon_post' if postprocess else 'recon', ops)
+        else:
+            self._run(ops)
+        return self.post if postprocess else self.Y.t[: self.B * self.g.output_text_size * self.V].view(
+            self.B, self.g.output_text_size, self.V)
+
+    def decode_latent(self, z: torch.Tensor) -> torch.Tensor:
+        """vae_decoder_.predict_on_batch(z): z [B, latent] fp32 -> y [B, T_out, V] fp32."""
+        self.mlv.zero_()
+        self.mlv[:, :self.D].copy_(z)
+        self._run(self.ops_lat_infer + self.ops_dec)
+        return self.Y.t[: self.B * self.g.output_text_size * self.V].view(self.B, self.g.output_text_size, self.V)
+
+    def y_pred(self) -> torch.Tensor:
+        return self.Y.t[: self.B * self.g.output_text_size * self.V].view(self.B, self.g.output_text_size, self.V)
+
+
+class VocabDecoder:
+    """a10-ii: nearest vocabulary row of each query (gensim `similar_by_vector` arithmetic, :587), optionally with the
+    vocabulary sharded over ranks (each rank owns rows [n_base, n_base + N_local))."""
+
+    def __init__(self, vocab_norm: np.ndarray, max_queries: int, dtype: str = 'bf16', device: str = 'cuda:0', n_base: int = 0):
+        if not torch.cuda.is_available():
+            raise L.C1VError('VocabDecoder needs a GPU')
+        self.lib = L.load()
+        self.dev = torch.device(device)
+        self.tdt = torch.bfloat16 if dtype == 'bf16' else torch.float32
+        self.code = L.BF16 if dtype == 'bf16' else L.F32
+        W = np.asarray(vocab_norm, dtype=np.float32)
+        self.N, self.K = W.shape
+        self.kp = _pad(self.K, 32)
+        self.n_pad = _pad(self.N, 64)
+        self.n_base = int(n_base)
+        host = np.zeros((self.n_pad, self.kp), dtype=np.float32)
+        host[:self.N, :self.K] = W
+        self.w = torch.from_numpy(host).to(self.dev).to(self.tdt).contiguous()
+        self.Mmax = int(max_queries)
+        self.m_pad = _pad(self.Mmax, 128)
+        self.q = torch.zeros(self.m_pad * self.kp, dtype=self.tdt, device=self.dev)
+        fused = self.code == L.BF16 and self.kp in (32, 64, 320)
+        tiles = self.n_pad // 64
+        self.splits = max(1, min(tiles, (2 * 256) // max(1, self.m_pad // 128), 16)) if fused else 1
+        self.part_score = torch.zeros(self.splits * self.m_pad, dtype=torch.float32, device=self.dev)
+        self.part_idx = torch.zeros(self.splits * self.m_pad, dtype=torch.int32, device=self.dev)
+        self.score = torch.zeros(self.m_pad, dtype=torch.float32, device=self.dev)
+        self.idx = torch.zeros(self.m_pad, dtype=torch.int32, device=self.dev)
+        if fused:
+            self.n_chunk, self.logits = 0, None
+        else:
+            self.n_chunk = int(min(self.n_pad, max(1024, (1 << 28) // self.m_pad)))
+            self.logits = torch.zeros(self.m_pad * self.n_chunk, dtype=torch.float32, device=self.dev)
+
+    def load_queries(self, q: torch.Tensor):
+        """q [M, K] (any float dtype, device or host): rows are used as given (normalise beforehand)."""
+        M = q.shape[0]
+        if M > self.Mmax or q.shape[1] != self.K:
+            raise ValueError('queries must be [<= {0}, {1}]'.format(self.Mmax, self.K))
+        qv = self.q.view(self.m_pad, self.kp)
+        qv[:M, :self.K].copy_(q.to(self.dev))
+        self.M = M
+
+    def run(self):
+        a = L.VocabArgmaxArgs(self.q.data_ptr(), self.code, self.M, self.kp, self.w.data_ptr(), self.N, self.n_pad,
+                              self.n_base, self.part_score.data_ptr(), self.part_idx.data_ptr(), self.m_pad, self.splits,
+                              self.score.data_ptr(), self.idx.data_ptr(),
+                              self.logits.data_ptr() if self.logits is not None else None, self.n_chunk)
+        L.call('c1v_vocab_argmax', C.byref(a), C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream))
+        return self.score[:self.M], self.idx[:self.M]

@@ -1,0 +1,294 @@
+/* libc1dvae -- C ABI of the MI355X-native Conv1D text-VAE hot path.
+ *
+ * The reference (nsu-ai-team/conv1d-text-vae) is pure Python on Keras/TensorFlow and has no FFI of its own
+ * (SURVEY.md section 8b).  Each entry point below replaces the Keras layer / optimizer call the reference
+ * makes at the cited line of conv1d_text_vae/conv1d_text_vae.py; the Python host in conv1d_text_vae_amd/
+ * binds them with ctypes.
+ *
+ * Conventions
+ *   - every op is `int c1v_<op>(const c1v_<op>_args*, void* hipStream)`; 0 = ok, negative = error and
+ *     `c1v_last_error()` (thread-local) says why.  No exceptions cross the ABI.
+ *   - the library never allocates device memory: every pointer is caller-owned device memory
+ *     (the Python host allocates with torch).  All launches go to the stream given; nothing synchronises,
+ *     so every op can be captured into a HIP graph.
+ *   - dtype: 0 = float32, 1 = bfloat16.  "T" below is the compute/storage dtype of a model instance.
+ *   - shape checks happen on the host before any launch; a failed check launches nothing.
+ */
+#ifndef C1DVAE_H
+#define C1DVAE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define C1V_F32 0
+#define C1V_BF16 1
+
+/* Channels-last padded sequence buffer.  Element (b, t, c) lives at
+ *     data[b * bstride + (off + t) * cp + c]          (element units of `dtype`)
+ * Rows outside [off, off+len) of a sample and channels >= c are kept ZERO by every producer; the
+ * allocation carries `C1V_SLACK_ROWS` zero rows after the last sample so that window reads may run over. */
+typedef struct c1v_seq {
+    void*   data;
+    int32_t dtype;
+    int32_t batch;
+    int64_t bstride;   /* elements between samples (= pitch * cp for a conv operand buffer) */
+    int32_t off;       /* first valid row inside a sample */
+    int32_t len;       /* valid rows */
+    int32_t cp;        /* row pitch in elements (multiple of 32 for a conv/GEMM operand) */
+    int32_t c;         /* valid channels */
+} c1v_seq;
+
+#define C1V_SLACK_ROWS 8
+
+/* row modes of the fused epilogue */
+#define C1V_ROW_STORE   0   /* dst row = u                                                    */
+#define C1V_ROW_POOL2   1   /* MaxPool1D(2): rows (2i,2i+1) -> i, writes `sel`        (a2)     */
+#define C1V_ROW_UP2     2   /* UpSampling1D(2)+Cropping1D: row u -> 2u, 2u+1 (< dst.len) (a6)  */
+#define C1V_ROW_PAIRSUM 3   /* backward of UP2: rows (2i,2i+1) summed -> i                     */
+#define C1V_ROW_UNPOOL  4   /* backward of POOL2: row u -> 2u+sel (other row <- 0)             */
+
+/* Generic fused epilogue applied by conv / dense kernels to each accumulator element (u, n) of sample b:
+ *   v += bias[n]; v = relu(v) if relu;
+ *   column split: if reshape_w > 0 then (t, c) = divmod(n, reshape_w) else (t, c) = (u, n)
+ *   row mode (above) maps t -> destination row(s);
+ *   v *= (act(b, row, c) > 0) * act_scale    if act.data   (ReLU / dropout backward mask)
+ *   v  = keep[b, row, c] ? v * keep_scale : 0  if keep      (Dropout forward, :1243)
+ */
+typedef struct c1v_epilogue {
+    const float*   bias;        /* [n] or NULL */
+    int32_t        relu;
+    int32_t        row_mode;
+    int32_t        reshape_w;   /* 0 = off */
+    c1v_seq        dst;         /* destination; dst.dtype may differ from the compute dtype */
+    c1v_seq        act;         /* optional mask source (act.data == NULL: none) */
+    int32_t        act_rowmul;  /* mask row = act.off + row * act_rowmul (2 when the activation is stored upsampled) */
+    float          act_scale;
+    uint8_t*       sel;         /* POOL2: written; UNPOOL: read.  index b*sel_bstride + row*sel_cp + c */
+    int64_t        sel_bstride;
+    int32_t        sel_cp;
+    const uint8_t* keep;        /* dropout keep mask, same indexing as sel */
+    float          keep_scale;
+} c1v_epilogue;
+
+/* ---- a1 / a6 / a7: Conv1D('valid'|'same') and Conv2DTranspose((k,1)) forward (:1227-1280) -------------
+ * out(b,u,n) = sum_{j<k, c<x.cp} X[b][a_off + u + j][c] * w_op[n][j*x.cp + c]   for u < n_rows
+ * X rows are buffer rows (x.off is NOT added: zero border rows implement 'same'/'full' padding, so
+ * valid conv: a_off=0; same conv: x.off=(k-1)/2; transposed conv: x.off=k-1 with w_op taps flipped).
+ * w_op [n_out][k*x.cp] in the compute dtype comes from c1v_pack_weights.  The same entry point computes
+ * dgrad (X = padded output-gradient buffer, w_op = dgrad operand copy). */
+typedef struct c1v_conv1d_args {
+    c1v_seq      x;
+    int32_t      a_off;
+    int32_t      n_rows;      /* output rows per sample */
+    int32_t      k;
+    const void*  w_op;
+    int32_t      n_out;       /* valid output channels N */
+    c1v_epilogue epi;
+} c1v_conv1d_args;
+int c1v_conv1d_fwd(const c1v_conv1d_args*, void* stream);
+int c1v_conv1d_dgrad(const c1v_conv1d_args*, void* stream);     /* same kernel family, named per SURVEY 8b */
+int c1v_deconv1d_fwd(const c1v_conv1d_args*, void* stream);     /* requires x.off == k-1 */
+int c1v_deconv1d_dgrad(const c1v_conv1d_args*, void* stream);
+
+/* ---- a3 / a5: Dense forward / dgrad (:1244-1245, :1253) -------------------------------------------------
+ * out(b,n) = sum_k A[b*lda + k] * w_op[n][k], k < K (K multiple of 8 elements, rows 16-byte aligned). */
+typedef struct c1v_dense_args {
+    const void*  a;
+    int32_t      dtype;
+    int32_t      rows;        /* M = batch */
+    int64_t      lda;
+    int32_t      K;
+    const void*  w_op;        /* [n_out][ldw] */
+    int64_t      ldw;
+    int32_t      n_out;
+    c1v_epilogue epi;
+} c1v_dense_args;
+int c1v_dense_fwd(const c1v_dense_args*, void* stream);
+int c1v_dense_dgrad(const c1v_dense_args*, void* stream);
+
+/* ---- wgrad of conv / deconv / dense: dW partial sums (TN GEMM, split over rows) ---------------------------
+ * for tap in [0,taps): out[s][tap_off(tap) + i*si + j*sj] = sum_{r in split s} A[(r + a_shift0 + tap)*lda + i] * D[r*ldd + j]
+ * with tap_off(tap) = (flip ? taps-1-tap : tap) * tap_stride, i < I, j < J.  The caller sums the `splits`
+ * slabs with c1v_grad_finalize.  Rows r run over [r_begin, r_end) of the flat buffers (zero border rows of D
+ * make cross-sample terms vanish; A and D must share the per-sample pitch). */
+typedef struct c1v_wgrad_args {
+    const void* a;  int64_t lda;  int32_t I;
+    const void* d;  int64_t ldd;  int32_t J;
+    int32_t     dtype;
+    int64_t     r_begin, r_end;
+    int32_t     a_shift0;
+    int32_t     taps;
+    int32_t     flip;
+    int64_t     tap_stride, si, sj;
+    float*      out;
+    int64_t     slab_stride;
+    int32_t     splits;
+} c1v_wgrad_args;
+int c1v_wgrad(const c1v_wgrad_args*, void* stream);
+int c1v_conv1d_wgrad(const c1v_wgrad_args*, void* stream);
+int c1v_deconv1d_wgrad(const c1v_wgrad_args*, void* stream);
+int c1v_dense_wgrad(const c1v_wgrad_args*, void* stream);
+
+/* column sums (bias gradients): out[s][c] = sum_{rows of split s} buf[row*ld + c], c < C */
+typedef struct c1v_colsum_args {
+    const void* buf; int32_t dtype; int64_t rows; int64_t ld; int32_t C;
+    float* out; int64_t slab_stride; int32_t splits;
+} c1v_colsum_args;
+int c1v_colsum(const c1v_colsum_args*, void* stream);
+
+/* ---- operand copies of the fp32 master weights ------------------------------------------------------------
+ * dst[n*ldk + tap'*cp + c] = src[tap*s_tap + c*s_c + n*s_n],  tap' = flip ? taps-1-tap : tap,
+ * for n < n_count, tap < taps, c < c_count.  Padding entries of dst are never written (stay zero). */
+typedef struct c1v_pack_desc {
+    const float* src; void* dst; int32_t dtype;
+    int32_t n_count, taps, c_count, cp, flip;
+    int64_t ldk, s_tap, s_c, s_n;
+} c1v_pack_desc;
+/* `descs` is a DEVICE array of n_desc descriptors; max_elems = max over descs of n_count*taps*c_count */
+int c1v_pack_weights(const c1v_pack_desc* descs, int32_t n_desc, int64_t max_elems, void* stream);
+
+/* input featuriser output -> operand buffer: dst(b,t,c) = src[(b*T + t)*C + c] (float32 -> T, zero padded) */
+typedef struct c1v_pack_input_args { const float* src; int32_t T, C; c1v_seq dst; } c1v_pack_input_args;
+int c1v_pack_input(const c1v_pack_input_args*, void* stream);
+/* gather variant (device-side batch assembly, SequenceForVAE :1374-1390): dst(b,t,:) = table[ids[b*T+t]] or 0 if id<0 */
+typedef struct c1v_gather_input_args { const float* table; int64_t ld; const int32_t* ids; int32_t T, C; c1v_seq dst; } c1v_gather_input_args;
+int c1v_gather_input(const c1v_gather_input_args*, void* stream);
+
+/* ---- a3+a4: latent head (:1188-1191, :1202, :1246, :1254) ---------------------------------------------------
+ * mlv [B][2*D] f32 (z_mean | z_log_var, bias already added by the dense epilogue)
+ * fwd: z = m + exp(std_scale*lv)*eps ; zd = keep_d ? z/keep_prob : 0 -> zd_out (T, [B][ldz]); z_out f32 optional
+ *      kl_out[b] = mean_d(1 + lv - m^2 - exp(lv))
+ * bwd: dz = dzd * keep_d/keep_prob; dm = dz + kl_w*2m/(D*Bglobal); dlv = dz*eps*std_scale*exp(std_scale*lv) + kl_w*(exp(lv)-1)/(D*Bglobal)
+ *      -> dmlv (T, [B][ldd])  (std_scale = 1.0 is the reference) */
+typedef struct c1v_latent_args {
+    const float* mlv; int32_t B, D;
+    const float* eps;            /* [B][D] */
+    const uint8_t* keep_d;       /* [B][D] or NULL (inference) */
+    float keep_prob; float std_scale;
+    void* zd_out; int32_t dtype; int64_t ldz;
+    float* z_out;                /* [B][D] or NULL */
+    float* kl_out;               /* [B] or NULL */
+    /* backward only */
+    const float* dzd;            /* [B][D] f32 */
+    int32_t B_global;
+    void* dmlv; int64_t ldd;
+} c1v_latent_args;
+int c1v_latent_head_fwd(const c1v_latent_args*, void* stream);
+int c1v_latent_head_bwd(const c1v_latent_args*, void* stream);
+
+/* ---- a8: cosine-softmax cross-entropy against the vocabulary matrix (:1193-1203, :1319, :1326) --------------
+ * Step 1  c1v_l2norm_rows: yhat = y / sqrt(max(sum y^2, 1e-12)) * qscale  -> T [M][kp] (zero padded), rnorm[M]
+ * Step 2  c1v_cos_softmax_accum: for every row m and vocabulary row n:  e = exp2(yhat_m . w_n)   (qscale = log2(e)/tau)
+ *           UT[s][c][m] = sum_{n in split s} e * w_n[c]   (c < kp; column `ones_col` of w holds 1.0 => UT[.][ones_col][m] = sum e)
+ *         bf16: one fused MFMA kernel that never materialises the [M,N] logits; f32: NT GEMM + exp + TN GEMM
+ *         through the caller's scratch `logits` ([n_chunk][m_pad] f32).
+ * Step 3  c1v_cos_softmax_finish: per row: p_t, clip, xent, mask; per sample loss; dy = d loss / d y (T, padded conv-operand layout)
+ */
+typedef struct c1v_l2norm_args {
+    const float* y; int32_t M, V; int64_t ldy;
+    void* yhat; int32_t dtype; int32_t kp;
+    float* rnorm;           /* 1/sqrt(max(sum y^2, eps)) */
+    float qscale;
+} c1v_l2norm_args;
+int c1v_l2norm_rows(const c1v_l2norm_args*, void* stream);
+
+typedef struct c1v_xent_accum_args {
+    const void* yhat; int32_t dtype; int32_t M, kp;
+    const void* w;    /* [n_pad][kp] T, rows >= N zero, column ones_col = 1.0 on rows < N */
+    int32_t N, n_pad;
+    float* ut;        /* [splits][kp][m_pad] f32 */
+    int32_t m_pad, splits;
+    int32_t need_u;   /* 0: only the sum-exp row `ones_col` is produced (validation loss) */
+    int32_t ones_col;
+    float* logits;    /* f32 path scratch [n_chunk][m_pad] */
+    int32_t n_chunk;
+} c1v_xent_accum_args;
+int c1v_cos_softmax_accum(const c1v_xent_accum_args*, void* stream);
+
+typedef struct c1v_xent_finish_args {
+    const float* ut; int32_t splits, kp, m_pad, ones_col;
+    const void* yhat; const void* w; int32_t dtype;
+    const float* rnorm; float qscale;
+    const int32_t* ids;       /* [B*T] target id or -1 */
+    int32_t B, T, V;
+    int32_t B_global;
+    float* xent_rows;         /* [B*T] masked per-row cross entropy */
+    float* xent_b;            /* [B] per-sample sum_t xent*mask / sum_t mask */
+    c1v_seq dy;               /* or dy.data == NULL for loss only */
+} c1v_xent_finish_args;
+int c1v_cos_softmax_finish(const c1v_xent_finish_args*, void* stream);
+int c1v_cos_softmax_xent_fwd(const c1v_xent_accum_args*, void* stream);   /* need_u = 0 alias */
+int c1v_cos_softmax_xent_bwd(const c1v_xent_accum_args*, void* stream);   /* need_u = 1 alias */
+
+/* loss scalars (single block, fixed summation order):
+ *   xent_b[b] = sum_t xent_rows[b,t] / #(ids[b,t] >= 0)           (:1200-1201)
+ *   out3[0] = sum_b (xent_b[b] - kl_b[b]) / B_global  (:1203 + Keras batch mean); out3[1], out3[2] = the two terms */
+int c1v_loss_reduce(const float* xent_rows, const int32_t* ids, const float* kl_b, int32_t B, int32_t T, int32_t B_global,
+                    float* out3, float* xent_b, void* stream);
+
+/* ---- a9: Nadam(clipnorm) over the flat parameter buffer (:1329) ----------------------------------------------
+ * c1v_grad_finalize: grad[seg.offset + i] = sum_{s<splits} sum_{r<reps} slab[s*slab_stride + r*rep_stride + i]
+ *                    and sq_partial[block] = partial sum of grad^2 (when sq_partial != NULL)
+ * c1v_sqnorm_partial: partial sums of squares of an arbitrary f32 buffer (after an all-reduce)
+ * c1v_nadam_step:    Keras-2.2 Nadam; clip scale = clipnorm/norm if norm >= clipnorm, norm = sqrt(sum sq_partial)*grad_scale */
+typedef struct c1v_seg_desc { const float* slab; int64_t slab_stride; int32_t splits; int32_t reps; int64_t rep_stride; int64_t offset; int64_t count; int32_t frozen; int32_t pad; } c1v_seg_desc;
+int c1v_grad_finalize(const c1v_seg_desc* segs /*device*/, int32_t n_seg, int64_t max_count, float* grad, float* sq_partial, int32_t n_partial, void* stream);
+int c1v_sqnorm_partial(const float* x, int64_t n, float* sq_partial, int32_t n_partial, void* stream);
+typedef struct c1v_nadam_args {
+    float* p; const float* g; float* m; float* v; int64_t n;
+    const float* sq_partial; int32_t n_partial;
+    float grad_scale;          /* 1/world_size after a sum all-reduce */
+    float clipnorm;
+    const float* sched;        /* DEVICE [8]: lr, mu_t, mu_t1, 1-m_schedule_new, 1-m_schedule_next, 1-beta2^t, t, unused */
+    float beta1, beta2, eps;
+    float* norm_out;           /* optional [1] */
+} c1v_nadam_args;
+int c1v_nadam_step(const c1v_nadam_args*, void* stream);
+/* state (DEVICE double[3]) = {iterations, m_schedule, lr}; writes the scalars of the NEXT step into sched[8] and
+ * advances the state, so that a captured HIP graph can be replayed without host-side scalar updates. */
+int c1v_nadam_advance(double* state, float* sched, void* stream);
+/* number of sq_partial entries c1v_grad_finalize writes for (n_seg, max_count) */
+int c1v_grad_finalize_partials(int32_t n_seg, int64_t max_count);
+
+/* ---- a10-i: EOS truncation + renormalisation (:542-565) ------------------------------------------------------
+ * y [B][T][V] f32 -> out [B][T][V-1] f32, end_idx[B] */
+int c1v_eos_truncate_normalize(const float* y, int32_t B, int32_t T, int32_t V, float* out, int32_t* end_idx, void* stream);
+
+/* ---- a10-ii: nearest vocabulary row (gensim similar_by_vector arithmetic, :587) -------------------------------
+ * score[m] = max_n q_m . w_n, idx[m] = lowest n attaining it (n_base added), over the caller's shard of rows.
+ * bf16: fused MFMA GEMM + arg-max; f32: NT GEMM into `logits` + arg-max kernel. */
+typedef struct c1v_vocab_argmax_args {
+    const void* q; int32_t dtype; int32_t M, kp;
+    const void* w; int32_t N, n_pad; int32_t n_base;
+    float* part_score; int32_t* part_idx;   /* [splits][m_pad] scratch */
+    int32_t m_pad, splits;
+    float* score; int32_t* idx;             /* [M] */
+    float* logits; int32_t n_chunk;
+} c1v_vocab_argmax_args;
+int c1v_vocab_argmax(const c1v_vocab_argmax_args*, void* stream);
+/* merge per-shard results gathered from R ranks: ties -> lowest global index */
+int c1v_argmax_merge(const float* scores /*[R][M]*/, const int32_t* idxs, int32_t R, int32_t M, float* score, int32_t* idx, void* stream);
+
+/* ---- counter-based RNG (Philox4x32-10): element e of stream uses block e>>2, word e&3 ------------------------
+ * out[i] is element (offset + ctr[0]*ctr_mul + i) of stream `stream_id` under key `seed` (ctr may be NULL).  The
+ * device-side counter lets a captured HIP graph draw fresh numbers on every replay; keying by the GLOBAL element
+ * index makes 1-GPU and N-GPU runs draw the same numbers for the same global sample. */
+int c1v_philox_normal(float* out, int64_t n, uint64_t seed, uint64_t stream_id, uint64_t offset,
+                      const uint64_t* ctr, uint64_t ctr_mul, void* stream);
+int c1v_philox_bernoulli(uint8_t* out, int64_t n, float keep_prob, uint64_t seed, uint64_t stream_id, uint64_t offset,
+                         const uint64_t* ctr, uint64_t ctr_mul, void* stream);
+int c1v_counter_add(uint64_t* ctr, uint64_t inc, void* stream);
+
+/* ---- misc ---------------------------------------------------------------------------------------------------- */
+const char* c1v_last_error(void);
+int c1v_version(void);
+/* info[0]=CU count, [1]=LDS bytes/CU, [2]=wavefront size, [3]=gfx arch number (950) */
+int c1v_device_info(int32_t device, int32_t* info4);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
