@@ -173,6 +173,14 @@ def load():
     if not os.path.isfile(LIB_PATH):
         raise C1VError('libc1dvae.so is not built (%s). Run `python -c "import __graft_entry__ as g; g.build()"` or '
                        '`make -C conv1d_text_vae_amd/csrc`. There is no CPU fallback.' % LIB_PATH)
+    # The HIP runtime must be the one PyTorch uses (streams and device pointers are shared with torch): load torch's
+    # bundled libamdhip64 into the global symbol scope first; libc1dvae.so itself does not link a HIP runtime.
+    import torch
+    tlib = os.path.join(os.path.dirname(torch.__file__), 'lib', 'libamdhip64.so')
+    if os.path.isfile(tlib):
+        C.CDLL(tlib, mode=C.RTLD_GLOBAL)
+    else:
+        C.CDLL('libamdhip64.so', mode=C.RTLD_GLOBAL)
     lib = C.CDLL(LIB_PATH)
     for name, (argtypes, restype) in SYMBOLS.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
