@@ -12,7 +12,8 @@ LIB_PATH = os.path.join(_HERE, 'libc1dvae.so')
 
 F32 = 0
 BF16 = 1
-SLACK_ROWS = 8
+SLACK_ROWS = 72
+CHUNK = 2048
 ROW_STORE, ROW_POOL2, ROW_UP2, ROW_PAIRSUM, ROW_UNPOOL = 0, 1, 2, 3, 4
 
 
@@ -30,7 +31,7 @@ class Epilogue(C.Structure):
 
 class ConvArgs(C.Structure):
     _fields_ = [('x', Seq), ('a_off', C.c_int32), ('n_rows', C.c_int32), ('k', C.c_int32), ('w_op', C.c_void_p),
-                ('n_out', C.c_int32), ('epi', Epilogue)]
+                ('ldw', C.c_int64), ('n_out', C.c_int32), ('epi', Epilogue)]
 
 
 class DenseArgs(C.Structure):
@@ -43,7 +44,8 @@ class WgradArgs(C.Structure):
                 ('d', C.c_void_p), ('ldd', C.c_int64), ('J', C.c_int32),
                 ('dtype', C.c_int32), ('r_begin', C.c_int64), ('r_end', C.c_int64), ('a_shift0', C.c_int32),
                 ('taps', C.c_int32), ('flip', C.c_int32), ('tap_stride', C.c_int64), ('si', C.c_int64),
-                ('sj', C.c_int64), ('out', C.c_void_p), ('slab_stride', C.c_int64), ('splits', C.c_int32)]
+                ('sj', C.c_int64), ('out', C.c_void_p), ('slab_stride', C.c_int64), ('splits', C.c_int32),
+                ('bias_out', C.c_void_p), ('bias_slab_stride', C.c_int64)]
 
 
 class ColsumArgs(C.Structure):
@@ -54,7 +56,8 @@ class ColsumArgs(C.Structure):
 class PackDesc(C.Structure):
     _fields_ = [('src', C.c_void_p), ('dst', C.c_void_p), ('dtype', C.c_int32), ('n_count', C.c_int32),
                 ('taps', C.c_int32), ('c_count', C.c_int32), ('cp', C.c_int32), ('flip', C.c_int32),
-                ('ldk', C.c_int64), ('s_tap', C.c_int64), ('s_c', C.c_int64), ('s_n', C.c_int64)]
+                ('ldk', C.c_int64), ('s_tap', C.c_int64), ('s_c', C.c_int64), ('s_n', C.c_int64),
+                ('first_block', C.c_int32), ('pad', C.c_int32)]
 
 
 class PackInputArgs(C.Structure):
@@ -96,14 +99,20 @@ class XentFinishArgs(C.Structure):
 class SegDesc(C.Structure):
     _fields_ = [('slab', C.c_void_p), ('slab_stride', C.c_int64), ('splits', C.c_int32), ('reps', C.c_int32),
                 ('rep_stride', C.c_int64), ('offset', C.c_int64), ('count', C.c_int64), ('frozen', C.c_int32),
-                ('pad', C.c_int32)]
+                ('first_block', C.c_int32)]
 
 
 class NadamArgs(C.Structure):
     _fields_ = [('p', C.c_void_p), ('g', C.c_void_p), ('m', C.c_void_p), ('v', C.c_void_p), ('n', C.c_int64),
-                ('sq_partial', C.c_void_p), ('n_partial', C.c_int32), ('grad_scale', C.c_float),
+                ('grad_scale', C.c_float),
                 ('clipnorm', C.c_float), ('sched', C.c_void_p), ('beta1', C.c_float), ('beta2', C.c_float),
                 ('eps', C.c_float), ('norm_out', C.c_void_p)]
+
+
+class RngDesc(C.Structure):
+    _fields_ = [('out', C.c_void_p), ('n', C.c_int64), ('kind', C.c_int32), ('thr', C.c_uint32),
+                ('stream_id', C.c_uint64), ('offset', C.c_uint64), ('ctr_mul', C.c_uint64),
+                ('first_block', C.c_int32), ('pad', C.c_int32)]
 
 
 class VocabArgmaxArgs(C.Structure):
@@ -127,7 +136,7 @@ SYMBOLS = {
     'c1v_deconv1d_wgrad': ([_P(WgradArgs), C.c_void_p], C.c_int),
     'c1v_dense_wgrad': ([_P(WgradArgs), C.c_void_p], C.c_int),
     'c1v_colsum': ([_P(ColsumArgs), C.c_void_p], C.c_int),
-    'c1v_pack_weights': ([C.c_void_p, C.c_int32, C.c_int64, C.c_void_p], C.c_int),
+    'c1v_pack_weights': ([C.c_void_p, C.c_int32, C.c_int32, C.c_void_p], C.c_int),
     'c1v_pack_input': ([_P(PackInputArgs), C.c_void_p], C.c_int),
     'c1v_gather_input': ([_P(GatherInputArgs), C.c_void_p], C.c_int),
     'c1v_latent_head_fwd': ([_P(LatentArgs), C.c_void_p], C.c_int),
@@ -139,11 +148,10 @@ SYMBOLS = {
     'c1v_cos_softmax_finish': ([_P(XentFinishArgs), C.c_void_p], C.c_int),
     'c1v_loss_reduce': ([C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
                          C.c_void_p, C.c_void_p], C.c_int),
-    'c1v_grad_finalize': ([C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p], C.c_int),
-    'c1v_grad_finalize_partials': ([C.c_int32, C.c_int64], C.c_int),
+    'c1v_grad_finalize': ([C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p], C.c_int),
     'c1v_sqnorm_partial': ([C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p], C.c_int),
     'c1v_nadam_step': ([_P(NadamArgs), C.c_void_p], C.c_int),
-    'c1v_nadam_advance': ([C.c_void_p, C.c_void_p, C.c_void_p], C.c_int),
+    'c1v_nadam_advance': ([C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p], C.c_int),
     'c1v_eos_truncate_normalize': ([C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p],
                                    C.c_int),
     'c1v_vocab_argmax': ([_P(VocabArgmaxArgs), C.c_void_p], C.c_int),
@@ -153,6 +161,7 @@ SYMBOLS = {
     'c1v_philox_bernoulli': ([C.c_void_p, C.c_int64, C.c_float, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p,
                               C.c_uint64, C.c_void_p], C.c_int),
     'c1v_counter_add': ([C.c_void_p, C.c_uint64, C.c_void_p], C.c_int),
+    'c1v_philox_multi': ([C.c_void_p, C.c_int32, C.c_int32, C.c_uint64, C.c_void_p, C.c_void_p], C.c_int),
     'c1v_last_error': ([], C.c_char_p),
     'c1v_version': ([], C.c_int),
     'c1v_device_info': ([C.c_int32, _P(C.c_int32)], C.c_int),

@@ -55,7 +55,8 @@ static int conv_common(const c1v_conv1d_args* a, void* stream, const char* what)
     const int es = c1v_esize(a->x.dtype);
     NtParams p{};
     p.A = (const char*)a->x.data; p.a_bstride_b = a->x.bstride * es; p.lda_b = (int64_t)a->x.cp * es; p.a_off = a->a_off;
-    p.W = (const char*)a->w_op; p.ldw_b = (int64_t)a->k * a->x.cp * es; p.Kb = p.ldw_b;
+    p.W = (const char*)a->w_op; p.ldw_b = a->ldw * es; p.Kb = (int64_t)a->k * a->x.cp * es;
+    C1V_REQUIRE(a->ldw >= (int64_t)a->k * a->x.cp, "%s: ldw (%lld) is smaller than k*cp", what, (long long)a->ldw);
     const int64_t M = (int64_t)a->x.batch * Le;
     C1V_REQUIRE(M < (1ll << 31), "%s: too many rows", what);
     if (c1v_fill_epi(a->epi, p.e, (int)M, Le, a->n_rows, a->n_out)) return -1;
@@ -105,6 +106,7 @@ extern "C" int c1v_wgrad(const c1v_wgrad_args* a, void* stream) {
     p.rows_per_split = c1v_cdiv(c1v_cdiv(a->r_end - a->r_begin, a->splits), br) * br;
     p.a_shift0 = a->a_shift0; p.taps = a->taps; p.flip = a->flip; p.tap_stride = a->tap_stride; p.si = a->si; p.sj = a->sj;
     p.out = a->out; p.slab_stride = a->slab_stride; p.splits = a->splits;
+    p.bias_out = a->bias_out; p.bias_slab_stride = a->bias_slab_stride;
     return c1v_launch_tn(a->dtype, p, (hipStream_t)stream);
 }
 extern "C" int c1v_conv1d_wgrad(const c1v_wgrad_args* a, void* s) { return c1v_wgrad(a, s); }

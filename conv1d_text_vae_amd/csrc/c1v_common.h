@@ -82,6 +82,7 @@ struct TnParams {
     int64_t r_begin, r_end; int64_t rows_per_split;
     int a_shift0; int taps; int flip; int64_t tap_stride, si, sj;
     float* out; int64_t slab_stride; int splits;
+    float* bias_out; int64_t bias_slab_stride;
 };
 
 int c1v_launch_nt(int dtype, const NtParams& p, hipStream_t st);

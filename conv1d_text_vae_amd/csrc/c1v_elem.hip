@@ -73,10 +73,17 @@ extern "C" int c1v_gather_input(const c1v_gather_input_args* a, void* stream) {
 // ------------------------------------------------------------------------------------------------------
 // weight operand copies (descriptor table on the device; blockIdx.y = descriptor)
 // ------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void pack_weights_kernel(const c1v_pack_desc* __restrict__ descs) {
-    const c1v_pack_desc d = descs[blockIdx.y];
+__global__ __launch_bounds__(256) void pack_weights_kernel(const c1v_pack_desc* __restrict__ descs, int n_desc) {
+    // blocks are dealt to descriptors by their `first_block`; one block copies C1V_CHUNK consecutive destination elements
+    int di = 0;
+    while (di + 1 < n_desc && (int)blockIdx.x >= descs[di + 1].first_block) ++di;
+    const c1v_pack_desc d = descs[di];
     const int64_t total = (int64_t)d.n_count * d.taps * d.c_count;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t base = (int64_t)((int)blockIdx.x - d.first_block) * C1V_CHUNK;
+#pragma unroll
+    for (int k = 0; k < C1V_CHUNK / 256; ++k) {
+        const int64_t i = base + k * 256 + threadIdx.x;
+        if (i >= total) break;
         // destination-major enumeration (n, tap', c) -> coalesced writes
         const int c = (int)(i % d.c_count);
         const int64_t r = i / d.c_count;
@@ -88,10 +95,9 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const c1v_pack_desc* 
     }
 }
 
-extern "C" int c1v_pack_weights(const c1v_pack_desc* descs, int32_t n_desc, int64_t max_elems, void* stream) {
-    C1V_REQUIRE(descs && n_desc > 0 && max_elems > 0, "pack_weights: bad argument");
-    dim3 grid(grid_for(max_elems) > 64 ? 64 : grid_for(max_elems), (unsigned)n_desc);
-    hipLaunchKernelGGL(pack_weights_kernel, grid, dim3(256), 0, (hipStream_t)stream, descs);
+extern "C" int c1v_pack_weights(const c1v_pack_desc* descs, int32_t n_desc, int32_t total_blocks, void* stream) {
+    C1V_REQUIRE(descs && n_desc > 0 && total_blocks > 0, "pack_weights: bad argument");
+    hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, descs, n_desc);
     C1V_LAUNCH_CHECK();
     return 0;
 }
@@ -192,34 +198,54 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
     return r;
 }
 
-__global__ __launch_bounds__(256) void grad_finalize_kernel(const c1v_seg_desc* __restrict__ segs, float* __restrict__ grad,
+__global__ __launch_bounds__(256) void grad_finalize_kernel(const c1v_seg_desc* __restrict__ segs, int n_seg, float* __restrict__ grad,
                                                             float* __restrict__ sq_partial) {
     __shared__ float red[4];
-    const c1v_seg_desc d = segs[blockIdx.y];
+    int si = 0;
+    while (si + 1 < n_seg && (int)blockIdx.x >= segs[si + 1].first_block) ++si;
+    const c1v_seg_desc d = segs[si];
+    const int64_t base = (int64_t)((int)blockIdx.x - d.first_block) * C1V_CHUNK;
     float sq = 0.f;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < d.count; i += (int64_t)gridDim.x * blockDim.x) {
-        float g = 0.f;
-        if (!d.frozen)
-            for (int s = 0; s < d.splits; ++s)
-                for (int r = 0; r < d.reps; ++r) g += d.slab[(int64_t)s * d.slab_stride + (int64_t)r * d.rep_stride + i];
-        grad[d.offset + i] = g;
-        sq += g * g;
+    // slabs, segment offsets and counts are multiples of 4 floats except for a tail: float4 body, scalar tail
+    const bool vec = (d.count % 4 == 0) && (d.slab_stride % 4 == 0) && (d.rep_stride % 4 == 0) && (d.offset % 4 == 0) &&
+                     (((uintptr_t)d.slab) % 16 == 0);
+#pragma unroll
+    for (int k = 0; k < C1V_CHUNK / 1024; ++k) {
+        const int64_t i = base + (int64_t)(k * 256 + threadIdx.x) * 4;
+        if (i >= d.count) continue;
+        if (vec) {
+            float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!d.frozen) {
+                const int ns = d.splits * d.reps;
+#pragma unroll 4
+                for (int s = 0; s < ns; ++s) {
+                    const int sp = s / d.reps, r = s - sp * d.reps;
+                    const float4 v = *(const float4*)(d.slab + (int64_t)sp * d.slab_stride + (int64_t)r * d.rep_stride + i);
+                    g.x += v.x; g.y += v.y; g.z += v.z; g.w += v.w;
+                }
+            }
+            *(float4*)(grad + d.offset + i) = g;
+            sq += (g.x * g.x + g.y * g.y) + (g.z * g.z + g.w * g.w);
+        } else {
+            for (int e = 0; e < 4 && i + e < d.count; ++e) {
+                float g = 0.f;
+                if (!d.frozen)
+                    for (int s = 0; s < d.splits; ++s)
+                        for (int r = 0; r < d.reps; ++r) g += d.slab[(int64_t)s * d.slab_stride + (int64_t)r * d.rep_stride + i + e];
+                grad[d.offset + i + e] = g;
+                sq += g * g;
+            }
+        }
     }
     sq = block_sum_256(sq, red);
-    if (threadIdx.x == 0 && sq_partial) sq_partial[blockIdx.y * gridDim.x + blockIdx.x] = sq;
+    if (threadIdx.x == 0 && sq_partial) sq_partial[blockIdx.x] = sq;
 }
 
-extern "C" int c1v_grad_finalize(const c1v_seg_desc* segs, int32_t n_seg, int64_t max_count, float* grad, float* sq_partial, int32_t n_partial, void* stream) {
-    C1V_REQUIRE(segs && grad && n_seg > 0 && max_count > 0, "grad_finalize: bad argument");
-    unsigned gx = grid_for(max_count); if (gx > 32) gx = 32;
-    C1V_REQUIRE(!sq_partial || n_partial == (int)(gx * n_seg), "grad_finalize: n_partial must be %u", gx * n_seg);
-    hipLaunchKernelGGL(grad_finalize_kernel, dim3(gx, (unsigned)n_seg), dim3(256), 0, (hipStream_t)stream, segs, grad, sq_partial);
+extern "C" int c1v_grad_finalize(const c1v_seg_desc* segs, int32_t n_seg, int32_t total_blocks, float* grad, float* sq_partial, void* stream) {
+    C1V_REQUIRE(segs && grad && n_seg > 0 && total_blocks > 0, "grad_finalize: bad argument");
+    hipLaunchKernelGGL(grad_finalize_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, segs, n_seg, grad, sq_partial);
     C1V_LAUNCH_CHECK();
     return 0;
-}
-extern "C" int c1v_grad_finalize_partials(int32_t n_seg, int64_t max_count) {
-    unsigned gx = grid_for(max_count); if (gx > 32) gx = 32;
-    return (int)(gx * n_seg);
 }
 
 __global__ __launch_bounds__(256) void sqnorm_partial_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ sq_partial) {
@@ -240,8 +266,14 @@ extern "C" int c1v_sqnorm_partial(const float* x, int64_t n, float* sq_partial, 
 // Nadam (Keras 2.2 `Nadam.get_updates`, reference :1329) with global-norm clipping (`clip_norm`)
 // ------------------------------------------------------------------------------------------------------
 // state (device): [0] = iterations (as double), [1] = m_schedule, [2] = lr
-__global__ void nadam_advance_kernel(double* __restrict__ state, float* __restrict__ sched, double beta1, double beta2, double decay) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__global__ __launch_bounds__(256) void nadam_advance_kernel(double* __restrict__ state, float* __restrict__ sched,
+                                                            const float* __restrict__ sq_partial, int n_partial,
+                                                            uint64_t* __restrict__ ctr, double beta1, double beta2, double decay) {
+    __shared__ float red[4];
+    float sq = 0.f;
+    for (int i = threadIdx.x; i < n_partial; i += 256) sq += sq_partial[i];
+    sq = block_sum_256(sq, red);
+    if (threadIdx.x != 0) return;
     const double t = state[0] + 1.0;
     const double mu_t = beta1 * (1.0 - 0.5 * pow(0.96, t * decay));
     const double mu_t1 = beta1 * (1.0 - 0.5 * pow(0.96, (t + 1.0) * decay));
@@ -254,24 +286,20 @@ __global__ void nadam_advance_kernel(double* __restrict__ state, float* __restri
     sched[4] = (float)(1.0 - m_next);
     sched[5] = (float)(1.0 - pow(beta2, t));
     sched[6] = (float)t;
-    sched[7] = 0.f;
+    sched[7] = sq;
     state[0] = t;
     state[1] = m_new;
+    if (ctr) ctr[0] += 1;
 }
-extern "C" int c1v_nadam_advance(double* state, float* sched, void* stream) {
-    C1V_REQUIRE(state && sched, "nadam_advance: null argument");
-    hipLaunchKernelGGL(nadam_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, state, sched, 0.9, 0.999, 0.004);
+extern "C" int c1v_nadam_advance(double* state, float* sched, const float* sq_partial, int32_t n_partial, uint64_t* ctr, void* stream) {
+    C1V_REQUIRE(state && sched && sq_partial && n_partial > 0, "nadam_advance: bad argument");
+    hipLaunchKernelGGL(nadam_advance_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, state, sched, sq_partial, n_partial, ctr, 0.9, 0.999, 0.004);
     C1V_LAUNCH_CHECK();
     return 0;
 }
 
 __global__ __launch_bounds__(256) void nadam_kernel(c1v_nadam_args a) {
-    __shared__ float red[4];
-    // every block reduces the (small) partial array in the same order -> identical clip scale everywhere
-    float sq = 0.f;
-    for (int i = threadIdx.x; i < a.n_partial; i += 256) sq += a.sq_partial[i];
-    sq = block_sum_256(sq, red);
-    const float norm = sqrtf(sq) * a.grad_scale;
+    const float norm = sqrtf(a.sched[7]) * a.grad_scale;
     float scale = a.grad_scale;
     if (a.clipnorm > 0.f && norm >= a.clipnorm) scale *= a.clipnorm / norm;
     if (a.norm_out && blockIdx.x == 0 && threadIdx.x == 0) a.norm_out[0] = norm;
@@ -290,8 +318,8 @@ __global__ __launch_bounds__(256) void nadam_kernel(c1v_nadam_args a) {
     }
 }
 extern "C" int c1v_nadam_step(const c1v_nadam_args* a, void* stream) {
-    C1V_REQUIRE(a && a->p && a->g && a->m && a->v && a->sq_partial && a->sched, "nadam_step: null argument");
-    C1V_REQUIRE(a->n > 0 && a->n_partial > 0, "nadam_step: bad size");
+    C1V_REQUIRE(a && a->p && a->g && a->m && a->v && a->sched, "nadam_step: null argument");
+    C1V_REQUIRE(a->n > 0, "nadam_step: bad size");
     hipLaunchKernelGGL(nadam_kernel, dim3(grid_for(a->n)), dim3(256), 0, (hipStream_t)stream, *a);
     C1V_LAUNCH_CHECK();
     return 0;
@@ -402,6 +430,48 @@ extern "C" int c1v_philox_bernoulli(uint8_t* out, int64_t n, float keep_prob, ui
     C1V_REQUIRE(out && n > 0 && keep_prob > 0.f && keep_prob <= 1.f, "philox_bernoulli: bad argument");
     const uint32_t thr = (uint32_t)(keep_prob * 16777216.0f);
     hipLaunchKernelGGL(philox_bernoulli_kernel, dim3(grid_for(n / 4 + 2)), dim3(256), 0, (hipStream_t)stream, out, n, thr, seed, stream_id, offset, ctr, ctr_mul);
+    C1V_LAUNCH_CHECK();
+    return 0;
+}
+
+// several RNG requests in one launch (one training step draws eps + two dropout masks)
+__global__ __launch_bounds__(256) void philox_multi_kernel(const c1v_rng_desc* __restrict__ descs, int n_desc, uint64_t seed,
+                                                           const uint64_t* __restrict__ ctr) {
+    int di = 0;
+    while (di + 1 < n_desc && (int)blockIdx.x >= descs[di + 1].first_block) ++di;
+    const c1v_rng_desc d = descs[di];
+    const uint64_t offset = d.offset + (ctr ? ctr[0] * d.ctr_mul : 0);
+    const uint64_t blk = (offset >> 2) + (uint64_t)((int)blockIdx.x - d.first_block) * 256 + threadIdx.x;
+    if (blk > ((offset + d.n - 1) >> 2)) return;
+    const uint4 w = philox4x32_10(make_uint4((uint32_t)blk, (uint32_t)(blk >> 32), (uint32_t)d.stream_id, (uint32_t)(d.stream_id >> 32)),
+                                  (uint32_t)seed, (uint32_t)(seed >> 32));
+    const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
+    if (d.kind == 0) {
+        float v[4];
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const float u1 = ((float)(ws[2 * p] >> 8) + 1.0f) * (1.0f / 16777216.0f);
+            const float u2 = (float)(ws[2 * p + 1] >> 8) * (1.0f / 16777216.0f);
+            const float r = sqrtf(-2.0f * logf(u1));
+            const float ang = 6.283185307179586f * u2;
+            v[2 * p] = r * cosf(ang); v[2 * p + 1] = r * sinf(ang);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint64_t e = blk * 4 + k;
+            if (e >= offset && e < offset + (uint64_t)d.n) ((float*)d.out)[e - offset] = v[k];
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint64_t e = blk * 4 + k;
+            if (e >= offset && e < offset + (uint64_t)d.n) ((uint8_t*)d.out)[e - offset] = (ws[k] >> 8) < d.thr ? 1 : 0;
+        }
+    }
+}
+extern "C" int c1v_philox_multi(const c1v_rng_desc* descs, int32_t n_desc, int32_t total_blocks, uint64_t seed, const uint64_t* ctr, void* stream) {
+    C1V_REQUIRE(descs && n_desc > 0 && total_blocks > 0, "philox_multi: bad argument");
+    hipLaunchKernelGGL(philox_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, descs, n_desc, seed, ctr);
     C1V_LAUNCH_CHECK();
     return 0;
 }

@@ -3,12 +3,20 @@
 //   gemm_nt : C[m][n] = sum_k A[m][k] * W[n][k]      conv / deconv / dense forward and dgrad (implicit GEMM:
 //             a conv window over a channels-last buffer IS a contiguous K = k*cp run, so conv = GEMM with
 //             overlapping A rows, lda = cp), with the fused epilogue of c1v_epilogue.
-//   gemm_tn : C[i][j] = sum_r A[r][i] * D[r][j]      wgrad, split over r into fp32 slabs.
+//   gemm_tn : C[i][j] = sum_r A[r][i] * D[r][j]      wgrad, split over r into fp32 slabs; optionally also the
+//             column sums of D (bias gradient) through one extra all-ones MFMA operand.
 //
-// Both are LDS-tiled, 256 threads = 4 waves (2x2), double-buffered through registers, and are written once
-// for "16 bytes of K per lane": bf16 feeds one v_mfma_f32_16x16x32_bf16 per 16-byte fragment pair, fp32 feeds
-// four v_mfma_f32_16x16x4_f32 (exact fp32 FMA chain) -- the k permutation inside a fragment is the same for
-// both operands, so the sum is unchanged.
+// Both are 256 threads = 4 waves (2x2) and written once for "16 bytes of K per lane": bf16 feeds one
+// v_mfma_f32_16x16x32_bf16 per 16-byte fragment pair, fp32 feeds four v_mfma_f32_16x16x4_f32 (exact fp32 FMA chain) --
+// the k permutation inside a fragment is the same for both operands, so the sum is unchanged.
+//
+// Staging: operand tiles go global -> LDS by LDS-DMA (global_load_lds_dwordx4, no VGPR staging) into a ring of NS
+// stages; a counted s_waitcnt vmcnt leaves NS-2 tiles in flight across the single barrier per K step.  At the shapes
+// of this model (M = batch*seq of a few thousand rows, K a few hundred) the GEMMs are latency- not MFMA-bound, so the
+// depth of the ring, not the MFMA schedule, is what sets their time.  LDS-DMA writes are lane-linear, therefore
+// swizzles are applied to the per-lane SOURCE address and padding lanes read a dummy address.
+// No load is predicated: out-of-range rows are clamped (their results are masked in the epilogue) and the K / row
+// tails rely on zero padding of the operand buffers (documented in include/c1dvae.h).
 #include "c1v_common.h"
 
 // ------------------------------------------------------------------------------------------------------
@@ -24,12 +32,9 @@ __device__ __forceinline__ void epi_store(const EpiDev& e, int b, int row, int c
     store_any(e.dst, e.dst_dtype, idx, v);
 }
 
-// single-row modes: STORE, UP2, UNPOOL
-__device__ __forceinline__ void epi_row(const EpiDev& e, int m, int n, float v) {
-    if (m >= e.M || n >= e.N) return;
-    const int b = m / e.Le;
-    const int u = m - b * e.Le;
-    if (u >= e.nrows) return;
+// single-row modes: STORE, UP2, UNPOOL.  (b, u) = sample / row of the GEMM row, already range-checked.
+__device__ __forceinline__ void epi_row(const EpiDev& e, int b, int u, int n, float v) {
+    if (n >= e.N) return;
     if (e.bias) v += e.bias[n];
     if (e.relu) v = fmaxf(v, 0.0f);
     if (e.exp2) v = exp2f(v);
@@ -52,11 +57,9 @@ __device__ __forceinline__ void epi_row(const EpiDev& e, int m, int n, float v) 
     }
 }
 
-// pair modes: POOL2, PAIRSUM.  m0 is even and Le is even, so (m0, m0+1) are rows (u, u+1) of one sample.
-__device__ __forceinline__ void epi_pair(const EpiDev& e, int m0, int n, float v0, float v1) {
-    if (m0 >= e.M || n >= e.N) return;
-    const int b = m0 / e.Le;
-    const int u = m0 - b * e.Le;
+// pair modes: POOL2, PAIRSUM.  u is even and Le is even, so (u, u+1) are rows of one sample.
+__device__ __forceinline__ void epi_pair(const EpiDev& e, int b, int u, int n, float v0, float v1) {
+    if (n >= e.N) return;
     const int t = u >> 1;
     if (t >= e.dst_len) return;
     if (e.bias) { const float bv = e.bias[n]; v0 += bv; v1 += bv; }
@@ -90,60 +93,64 @@ template <> __device__ __forceinline__ void mma16<float>(f32x4_t& acc, const uin
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
 }
 
-// LDS image of an operand tile: 128-byte rows (64 bf16 / 32 fp32 of K), 16-byte chunk index XOR-swizzled with
+__device__ __forceinline__ void glds16(const char* src, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, C1V_LDS_PTR(void, lds_wave_base), 16, 0, 0);
+}
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void block_barrier() {
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+// LDS image of an NT operand tile: 128-byte rows (64 bf16 / 32 fp32 of K), 16-byte chunk index XOR-swizzled with
 // (row>>1)&7 so that the 16 lanes of a ds_read_b128 group (rows r..r+15, one chunk column) hit 16 distinct slots.
 __device__ __forceinline__ int lds_off(int row, int ch) { return row * 128 + ((ch ^ ((row >> 1) & 7)) << 4); }
 
 // ------------------------------------------------------------------------------------------------------
 // NT kernel
 // ------------------------------------------------------------------------------------------------------
-template <typename T, int BM, int BN>
+template <typename T, int BM, int BN, int NS>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(const NtParams p) {
     constexpr int WTM = BM / 2, WTN = BN / 2, MI = WTM / 16, NJ = WTN / 16;
-    constexpr int A_IT = BM * 8 / 256, B_IT = BN * 8 / 256;
+    constexpr int A_IT = BM * 8 / 256, B_IT = BN * 8 / 256, LPT = A_IT + B_IT;
     constexpr int STAGE = (BM + BN) * 128;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-    const int lrow = tid >> 3, lch = tid & 7;
+    const int lrow = tid >> 3, lpos = tid & 7;
 
-    const char* ap[A_IT]; bool av[A_IT];
-    const char* bp[B_IT]; bool bv[B_IT];
+    // LDS-DMA: lane (lrow, lpos) of instruction i fills position lpos of tile row lrow + 32 i, which must hold logical
+    // chunk lpos ^ ((row>>1)&7) of that row (same 128-byte line, so coalescing is unchanged)
+    const char* ap[A_IT];
+    const char* bp[B_IT];
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
-        const int m = m0 + lrow + i * 32;
-        av[i] = m < p.e.M;
-        const int mm = av[i] ? m : 0;
-        const int b = mm / p.e.Le, u = mm - b * p.e.Le;
-        ap[i] = p.A + (int64_t)b * p.a_bstride_b + (int64_t)(p.a_off + u) * p.lda_b + lch * 16;
+        const int row = lrow + i * 32;
+        int m = m0 + row;
+        if (m >= p.e.M) m = p.e.M - 1;
+        const int b = m / p.e.Le, u = m - b * p.e.Le;
+        ap[i] = p.A + (int64_t)b * p.a_bstride_b + (int64_t)(p.a_off + u) * p.lda_b + ((lpos ^ ((row >> 1) & 7)) << 4);
     }
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
-        const int n = n0 + lrow + i * 32;
-        bv[i] = n < p.e.N;
-        bp[i] = p.W + (int64_t)(bv[i] ? n : 0) * p.ldw_b + lch * 16;
+        const int row = lrow + i * 32;
+        int n = n0 + row;
+        if (n >= p.e.N) n = p.e.N - 1;
+        bp[i] = p.W + (int64_t)n * p.ldw_b + ((lpos ^ ((row >> 1) & 7)) << 4);
     }
     const int KT = (int)((p.Kb + 127) / 128);
-    uint4 ra[A_IT], rb[B_IT];
-    const uint4 zero4 = make_uint4(0, 0, 0, 0);
 
-    auto gload = [&](int kt) {
-        const int64_t ko = (int64_t)kt * 128;
-        const bool kin = ko + lch * 16 < p.Kb;
-#pragma unroll
-        for (int i = 0; i < A_IT; ++i) ra[i] = (av[i] && kin) ? *(const uint4*)(ap[i] + ko) : zero4;
-#pragma unroll
-        for (int i = 0; i < B_IT; ++i) rb[i] = (bv[i] && kin) ? *(const uint4*)(bp[i] + ko) : zero4;
-    };
-    auto lstore = [&](int stage) {
-        char* sa = smem + stage * STAGE;
+    auto issue = [&](int kt) {
+        char* sa = smem + (kt % NS) * STAGE + wave * 1024;
         char* sb = sa + BM * 128;
+        const int64_t ko = (int64_t)kt * 128;
 #pragma unroll
-        for (int i = 0; i < A_IT; ++i) *(uint4*)(sa + lds_off(lrow + i * 32, lch)) = ra[i];
+        for (int i = 0; i < A_IT; ++i) glds16(ap[i] + ko, sa + i * 4096);
 #pragma unroll
-        for (int i = 0; i < B_IT; ++i) *(uint4*)(sb + lds_off(lrow + i * 32, lch)) = rb[i];
+        for (int i = 0; i < B_IT; ++i) glds16(bp[i] + ko, sb + i * 4096);
     };
 
     f32x4_t acc[MI][NJ];
@@ -152,12 +159,16 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const NtParams p) {
 #pragma unroll
         for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-    gload(0);
-    lstore(0);
-    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s)
+        if (s < KT) issue(s);
+
     for (int kt = 0; kt < KT; ++kt) {
-        if (kt + 1 < KT) gload(kt + 1);
-        const char* sa = smem + (kt & 1) * STAGE;
+        // tiles issued so far: min(KT, kt + NS - 1); all but the NS-2 youngest must have landed
+        if (kt + NS - 2 < KT) wait_vmcnt<(NS - 2) * LPT>(); else wait_vmcnt<0>();
+        block_barrier();
+        if (kt + NS - 1 < KT) issue(kt + NS - 1);
+        const char* sa = smem + (kt % NS) * STAGE;
         const char* sb = sa + BM * 128;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
@@ -172,24 +183,32 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const NtParams p) {
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) mma16<T>(acc[i][j], af[i], bf[j]);
         }
-        if (kt + 1 < KT) lstore((kt + 1) & 1);
-        __syncthreads();
     }
 
     // epilogue: acc[i][j][r] is C[m0 + wm*WTM + i*16 + (lane>>4)*4 + r][n0 + wn*WTN + j*16 + (lane&15)]
     const bool pairs = (p.e.row_mode == C1V_ROW_POOL2) || (p.e.row_mode == C1V_ROW_PAIRSUM);
+    const int nb = n0 + wn * WTN + (lane & 15);
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
         const int mb = m0 + wm * WTM + i * 16 + (lane >> 4) * 4;
+        if (pairs) {
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const int n = n0 + wn * WTN + j * 16 + (lane & 15);
-            if (pairs) {
-                epi_pair(p.e, mb, n, acc[i][j][0], acc[i][j][1]);
-                epi_pair(p.e, mb + 2, n, acc[i][j][2], acc[i][j][3]);
-            } else {
+            for (int r = 0; r < 4; r += 2) {
+                const int m = mb + r;
+                if (m >= p.e.M) continue;
+                const int b = m / p.e.Le, u = m - b * p.e.Le;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) epi_row(p.e, mb + r, n, acc[i][j][r]);
+                for (int j = 0; j < NJ; ++j) epi_pair(p.e, b, u, nb + j * 16, acc[i][j][r], acc[i][j][r + 1]);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = mb + r;
+                if (m >= p.e.M) continue;
+                const int b = m / p.e.Le, u = m - b * p.e.Le;
+                if (u >= p.e.nrows) continue;
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) epi_row(p.e, b, u, nb + j * 16, acc[i][j][r]);
             }
         }
     }
@@ -199,23 +218,28 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const NtParams p) {
 // TN kernel (wgrad): 128x128 output tile, K loop over rows r; operands are read "down the columns":
 //   bf16: ds_read_b64_tr_b16 (hardware transpose), fragment element 4w+q <-> row 16w + 4g + q of a 32-row step
 //   fp32: ds_read_b32 straight from the row-major tile (v_mfma_f32_16x16x4_f32 wants one k per lane group)
-// Row pitch = 128*esize + pad (bf16 +32 B, fp32 +64 B) keeps both read patterns conflict-free.
+// Row pitch = 128*esize + pad (bf16 +32 B, fp32 +64 B) keeps both read patterns conflict-free.  A tile image is
+// BR rows = 18 KiB, filled by 20 one-KiB LDS-DMA pieces (5 per wave; the last two land in a dead tail).
 // ------------------------------------------------------------------------------------------------------
 template <typename T> struct TnCfg;
-template <> struct TnCfg<bf16_raw> { static constexpr int BR = 64, PITCH = 128 * 2 + 32, CHUNKS = 16; };
-template <> struct TnCfg<float>    { static constexpr int BR = 32, PITCH = 128 * 4 + 64, CHUNKS = 32; };
+template <> struct TnCfg<bf16_raw> { static constexpr int BR = 64, PITCH = 128 * 2 + 32; };
+template <> struct TnCfg<float>    { static constexpr int BR = 32, PITCH = 128 * 4 + 64; };
+constexpr int TN_TILE = 20 * 1024;
+constexpr int TN_NS = 3;
 
 template <typename T>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(const TnParams p) {
     using Cfg = TnCfg<T>;
-    constexpr int BR = Cfg::BR, PITCH = Cfg::PITCH, CHUNKS = Cfg::CHUNKS;
+    constexpr int BR = Cfg::BR, PITCH = Cfg::PITCH;
     constexpr int ES = sizeof(T);
-    constexpr int IT = BR * CHUNKS / 256;             // 16-byte chunks per thread per operand (= 4)
-    constexpr int TILE = BR * PITCH;
-    constexpr int STAGE = 2 * TILE;
+    constexpr int CPR = PITCH / 16, DCH = 128 * ES / 16;
+    constexpr int STAGE = 2 * TN_TILE;
+    constexpr int PPW = 5, LPT = 2 * PPW;
+    static_assert(BR * PITCH == 18 * 1024, "tile image is 18 KiB");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wi = wave >> 1, wj = wave & 1;
     const int i0 = blockIdx.x * 128, j0 = blockIdx.y * 128;
     const int tap = blockIdx.z / p.splits, split = blockIdx.z - tap * p.splits;
@@ -225,33 +249,32 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const TnParams p) {
     const int64_t nrows = re > rb ? re - rb : 0;
     const int KT = (int)((nrows + BR - 1) / BR);
 
-    const int lrow = tid / CHUNKS, lch = tid % CHUNKS;
-    constexpr int ROWS_PER_IT = 256 / CHUNKS;
-    const bool a_col_ok = (i0 * ES + lch * 16) < p.Ia * ES;
-    const bool d_col_ok = (j0 * ES + lch * 16) < p.Ja * ES;
-    const char* abase = p.A + (int64_t)(p.a_shift0 + tap) * p.lda_b + (int64_t)i0 * ES + lch * 16;
-    const char* dbase = p.D + (int64_t)j0 * ES + lch * 16;
-    uint4 ra[IT], rd[IT];
-    const uint4 zero4 = make_uint4(0, 0, 0, 0);
+    // per-lane LDS-DMA sources (byte offsets from the first row of a tile); padding lanes read the row's first chunk
+    int64_t aoff[PPW], doff[PPW];
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+        const int Lc = (wave + 4 * i) * 64 + lane;
+        int row = Lc / CPR;
+        int pos = Lc - row * CPR;
+        if (row >= BR) { row = 0; pos = 0; }
+        int pa = pos, pd = pos;
+        if (pos >= DCH || i0 * ES + pos * 16 >= p.Ia * ES) pa = 0;
+        if (pos >= DCH || j0 * ES + pos * 16 >= p.Ja * ES) pd = 0;
+        aoff[i] = (int64_t)row * p.lda_b + pa * 16;
+        doff[i] = (int64_t)row * p.ldd_b + pd * 16;
+    }
+    const char* abase = p.A + (rb + p.a_shift0 + tap) * p.lda_b + (int64_t)i0 * ES;
+    const char* dbase = p.D + rb * p.ldd_b + (int64_t)j0 * ES;
 
-    auto gload = [&](int kt) {
+    auto issue = [&](int kt) {
+        char* sa = smem + (kt % TN_NS) * STAGE + wave * 1024;
+        char* sd = sa + TN_TILE;
+        const char* at = abase + (int64_t)kt * BR * p.lda_b;
+        const char* dt = dbase + (int64_t)kt * BR * p.ldd_b;
 #pragma unroll
-        for (int i = 0; i < IT; ++i) {
-            const int64_t r = rb + (int64_t)kt * BR + lrow + i * ROWS_PER_IT;
-            const bool ok = r < re;
-            ra[i] = (ok && a_col_ok) ? *(const uint4*)(abase + r * p.lda_b) : zero4;
-            rd[i] = (ok && d_col_ok) ? *(const uint4*)(dbase + r * p.ldd_b) : zero4;
-        }
-    };
-    auto lstore = [&](int stage) {
-        char* sa = smem + stage * STAGE;
-        char* sd = sa + TILE;
+        for (int i = 0; i < PPW; ++i) glds16(at + aoff[i], sa + i * 4096);
 #pragma unroll
-        for (int i = 0; i < IT; ++i) {
-            const int off = (lrow + i * ROWS_PER_IT) * PITCH + lch * 16;
-            *(uint4*)(sa + off) = ra[i];
-            *(uint4*)(sd + off) = rd[i];
-        }
+        for (int i = 0; i < PPW; ++i) glds16(dt + doff[i], sd + i * 4096);
     };
 
     f32x4_t acc[4][4];
@@ -259,13 +282,21 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const TnParams p) {
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    f32x4_t accb[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) accb[j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    const bool do_bias = p.bias_out != nullptr && blockIdx.x == 0 && tap == 0 && wi == 0;     // wave-uniform
 
-    if (KT > 0) { gload(0); lstore(0); }
-    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < TN_NS - 1; ++s)
+        if (s < KT) issue(s);
+
     for (int kt = 0; kt < KT; ++kt) {
-        if (kt + 1 < KT) gload(kt + 1);
-        const char* sa = smem + (kt & 1) * STAGE;
-        const char* sd = sa + TILE;
+        if (kt + TN_NS - 2 < KT) wait_vmcnt<(TN_NS - 2) * LPT>(); else wait_vmcnt<0>();
+        block_barrier();
+        if (kt + TN_NS - 1 < KT) issue(kt + TN_NS - 1);
+        const char* sa = smem + (kt % TN_NS) * STAGE;
+        const char* sd = sa + TN_TILE;
         if constexpr (sizeof(T) == 2) {
             const int g = lane >> 4, q = (lane & 15) >> 2, pq = lane & 3;
 #pragma unroll
@@ -273,8 +304,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const TnParams p) {
                 uint4 af[4], df[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const int colb = (wi * 64 + i * 16 + 4 * pq) * 2;
-                    const char* a0 = sa + (ks * 32 + 4 * g + q) * PITCH + colb;
+                    const char* a0 = sa + (ks * 32 + 4 * g + q) * PITCH + (wi * 64 + i * 16 + 4 * pq) * 2;
                     s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(C1V_LDS_PTR(s16x4_t, a0));
                     s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(C1V_LDS_PTR(s16x4_t, a0 + 16 * PITCH));
                     af[i] = make_uint4(__builtin_bit_cast(uint2, lo).x, __builtin_bit_cast(uint2, lo).y,
@@ -282,8 +312,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const TnParams p) {
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const int colb = (wj * 64 + j * 16 + 4 * pq) * 2;
-                    const char* d0 = sd + (ks * 32 + 4 * g + q) * PITCH + colb;
+                    const char* d0 = sd + (ks * 32 + 4 * g + q) * PITCH + (wj * 64 + j * 16 + 4 * pq) * 2;
                     s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(C1V_LDS_PTR(s16x4_t, d0));
                     s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(C1V_LDS_PTR(s16x4_t, d0 + 16 * PITCH));
                     df[j] = make_uint4(__builtin_bit_cast(uint2, lo).x, __builtin_bit_cast(uint2, lo).y,
@@ -293,9 +322,13 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const TnParams p) {
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) mma16<bf16_raw>(acc[i][j], af[i], df[j]);
+                if (do_bias) {
+                    const uint4 ones = make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) mma16<bf16_raw>(accb[j], ones, df[j]);
+                }
             }
         } else {
-#pragma unroll 2
             for (int ks = 0; ks < BR / 4; ++ks) {
                 float af[4], df[4];
                 const int row = ks * 4 + (lane >> 4);
@@ -308,10 +341,12 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const TnParams p) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], df[j], acc[i][j], 0, 0, 0);
+                if (do_bias) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) accb[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, df[j], accb[j], 0, 0, 0);
+                }
             }
         }
-        if (kt + 1 < KT) lstore((kt + 1) & 1);
-        __syncthreads();
     }
 
     const int tap_dst = p.flip ? (p.taps - 1 - tap) : tap;
@@ -329,27 +364,36 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const TnParams p) {
             }
         }
     }
+    if (do_bias && (lane >> 4) == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int jj = j0 + wj * 64 + j * 16 + (lane & 15);
+            if (jj < p.J) p.bias_out[(int64_t)split * p.bias_slab_stride + jj] = accb[j][0];
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------
 // host launchers
 // ------------------------------------------------------------------------------------------------------
 template <typename K> static void set_lds(K kern, int bytes) {
-    hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 
 template <typename T> static int launch_nt_t(const NtParams& p, hipStream_t st) {
     const int64_t tiles128 = c1v_cdiv(p.e.M, 128) * c1v_cdiv(p.e.N, 128);
     const bool pairs = p.e.row_mode == C1V_ROW_POOL2 || p.e.row_mode == C1V_ROW_PAIRSUM;
     C1V_REQUIRE(!pairs || (p.e.Le % 2 == 0), "pair epilogue needs an even row enumeration (Le=%d)", p.e.Le);
-    if (tiles128 >= 192) {
-        static bool once = (set_lds(gemm_nt_kernel<T, 128, 128>, 2 * 256 * 128), true); (void)once;
+    if (tiles128 >= 384) {
+        constexpr int NS = 3, LDS = NS * 256 * 128;
+        static bool once = (set_lds(gemm_nt_kernel<T, 128, 128, NS>, LDS), true); (void)once;
         dim3 grid((unsigned)c1v_cdiv(p.e.M, 128), (unsigned)c1v_cdiv(p.e.N, 128));
-        hipLaunchKernelGGL((gemm_nt_kernel<T, 128, 128>), grid, dim3(256), 2 * 256 * 128, st, p);
+        hipLaunchKernelGGL((gemm_nt_kernel<T, 128, 128, NS>), grid, dim3(256), LDS, st, p);
     } else {
-        static bool once = (set_lds(gemm_nt_kernel<T, 64, 64>, 2 * 128 * 128), true); (void)once;
+        constexpr int NS = 4, LDS = NS * 128 * 128;
+        static bool once = (set_lds(gemm_nt_kernel<T, 64, 64, NS>, LDS), true); (void)once;
         dim3 grid((unsigned)c1v_cdiv(p.e.M, 64), (unsigned)c1v_cdiv(p.e.N, 64));
-        hipLaunchKernelGGL((gemm_nt_kernel<T, 64, 64>), grid, dim3(256), 2 * 128 * 128, st, p);
+        hipLaunchKernelGGL((gemm_nt_kernel<T, 64, 64, NS>), grid, dim3(256), LDS, st, p);
     }
     C1V_LAUNCH_CHECK();
     return 0;
@@ -359,11 +403,13 @@ int c1v_launch_nt(int dtype, const NtParams& p, hipStream_t st) {
     C1V_REQUIRE(p.e.M > 0 && p.e.N > 0 && p.Kb > 0, "empty GEMM (M=%d N=%d Kb=%lld)", p.e.M, p.e.N, (long long)p.Kb);
     C1V_REQUIRE(p.Kb % 16 == 0 && p.lda_b % 16 == 0 && p.ldw_b % 16 == 0 && ((uintptr_t)p.A % 16) == 0 && ((uintptr_t)p.W % 16) == 0,
                 "GEMM operands must be 16-byte aligned (Kb=%lld lda=%lld ldw=%lld)", (long long)p.Kb, (long long)p.lda_b, (long long)p.ldw_b);
+    C1V_REQUIRE(p.ldw_b >= c1v_cdiv(p.Kb, 128) * 128, "weight operand rows must be zero-padded to whole 128-byte K tiles (ldw=%lld bytes, K=%lld bytes)",
+                (long long)p.ldw_b, (long long)p.Kb);
     return dtype == C1V_F32 ? launch_nt_t<float>(p, st) : launch_nt_t<bf16_raw>(p, st);
 }
 
 template <typename T> static int launch_tn_t(const TnParams& p, hipStream_t st) {
-    constexpr int lds = 2 * 2 * TnCfg<T>::BR * TnCfg<T>::PITCH;
+    constexpr int lds = TN_NS * 2 * TN_TILE;
     static bool once = (set_lds(gemm_tn_kernel<T>, lds), true); (void)once;
     dim3 grid((unsigned)c1v_cdiv(p.I, 128), (unsigned)c1v_cdiv(p.J, 128), (unsigned)(p.taps * p.splits));
     hipLaunchKernelGGL((gemm_tn_kernel<T>), grid, dim3(256), lds, st, p);

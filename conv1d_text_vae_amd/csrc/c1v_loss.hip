@@ -195,17 +195,27 @@ void vocab_stream_kernel(const bf16_raw* __restrict__ yhat, int M, const bf16_ra
 
     const int m_out = blockIdx.x * VS_BM + wave * 32 + l31;
     if constexpr (MODE == VS_ACCUM) {
-        float* o = ut + (int64_t)split * Cfg::KP * m_pad + m_out;
+        // U^T[c][m] sits with m on the lane; the consumer wants rows of U.  Transpose one 32x32 block at a time through
+        // this wave's private 4.5 KB of LDS (the W stages are dead after the loop's last barrier) and store 128-byte
+        // row segments: UT[split][m][c].
+        constexpr int TP = 36;                                  // floats per transposed row (32 + 4 pad)
+        float* tw = (float*)smem + wave * 32 * TP;
+        float* o = ut + ((int64_t)split * m_pad + blockIdx.x * VS_BM + wave * 32) * Cfg::KP;
 #pragma unroll
-        for (int cb = 0; cb < CB; ++cb)
+        for (int cb = 0; cb < CB; ++cb) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int c = cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                o[(int64_t)c * m_pad] = U[cb][r];
+            for (int g4 = 0; g4 < 4; ++g4)
+                *(float4*)(tw + l31 * TP + 8 * g4 + 4 * h) = make_float4(U[cb][4 * g4], U[cb][4 * g4 + 1], U[cb][4 * g4 + 2], U[cb][4 * g4 + 3]);
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int row = it * 8 + (lane >> 3), ch = lane & 7;
+                const float4 v = *(const float4*)(tw + row * TP + ch * 4);
+                *(float4*)(o + (int64_t)row * Cfg::KP + cb * 32 + ch * 4) = v;
             }
+        }
     } else if constexpr (MODE == VS_SUMEXP) {
         sumexp += __shfl_xor(sumexp, 32, 64);
-        if (h == 0) ut[((int64_t)split * Cfg::KP + ones_col) * m_pad + m_out] = sumexp;
+        if (h == 0) ut[((int64_t)split * m_pad + m_out) * Cfg::KP + ones_col] = sumexp;
     } else {
         const float ob = __shfl_xor(best, 32, 64);
         const int oi = __shfl_xor(best_idx, 32, 64);
@@ -226,91 +236,107 @@ __global__ __launch_bounds__(256) void xent_finish_kernel(const float* __restric
                                                           const float* __restrict__ rnorm, float qscale,
                                                           const int* __restrict__ ids, int B, int T_len, int V, int B_global,
                                                           float* __restrict__ xent_rows, c1v_seq dy) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* u = (float*)smem;                       // [32][kp + 1]
-    const int up = kp + 1;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // one wave per sample row; everything is row-wise and coalesced
+    const int lane = threadIdx.x & 63;
     const int M = B * T_len;
-    const int m0 = blockIdx.x * 32;
-    {   // phase 1: sum the split slabs, transposing [c][m] -> u[m][c]
-        const int ml = tid & 31, cg = tid >> 5;
-        const bool need_all = dy.data != nullptr;
-        for (int c = cg; c < kp; c += 8) {
-            float s = 0.f;
-            if (need_all || c == ones_col)
-                for (int sp = 0; sp < splits; ++sp) s += ut[((int64_t)sp * kp + c) * m_pad + m0 + ml];
-            u[ml * up + c] = s;
-        }
-    }
-    __syncthreads();
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const int b = m / T_len, t = m - b * T_len;
+    const int id = ids[m];
+    const bool mask = id >= 0;
     const float inv_q = 1.0f / qscale;
     const float inv_tau_eff = qscale * 0.6931471805599453f;     // 1/tau = qscale * ln 2
-    for (int rr = 0; rr < 8; ++rr) {
-        const int ml = wave * 8 + rr;
-        const int m = m0 + ml;
-        if (m >= M) break;
-        const int b = m / T_len, t = m - b * T_len;
-        const int id = ids[m];
-        const float* ur = u + ml * up;
-        const float sumexp = ur[ones_col];
-        float cnt = 0.f;
-        for (int tt = lane; tt < T_len; tt += 64) cnt += ids[b * T_len + tt] >= 0 ? 1.f : 0.f;
-        cnt = wave_sum(cnt);
-        float st = 0.f;
-        if (id >= 0)
-            for (int c = lane; c < V; c += 64)
-                st += ElemTraits<T>::load(yhat, (int64_t)m * kp + c) * ElemTraits<T>::load(w, (int64_t)id * kp + c);
-        st = wave_sum(st);
-        float p_t = exp2f(st) / sumexp;
-        const bool mask = id >= 0;
-        const bool live = mask && p_t > 1e-7f && p_t < (1.0f - 1e-7f);
-        const float p_c = fminf(fmaxf(p_t, 1e-7f), 1.0f - 1e-7f);
-        if (lane == 0) xent_rows[m] = mask ? -logf(p_c) : 0.0f;
-        if (dy.data == nullptr) continue;
-        const float coef = live ? inv_tau_eff / (cnt * (float)B_global) : 0.0f;
-        const float inv_se = 1.0f / sumexp;
-        float dot = 0.f;
-        for (int c = lane; c < V; c += 64) {
-            const float wt = id >= 0 ? ElemTraits<T>::load(w, (int64_t)id * kp + c) : 0.f;
-            const float dyh = coef * (ur[c] * inv_se - wt);
-            dot += dyh * ElemTraits<T>::load(yhat, (int64_t)m * kp + c) * inv_q;
+    float sumexp = 0.f;
+    for (int sp = 0; sp < splits; ++sp) sumexp += ut[((int64_t)sp * m_pad + m) * kp + ones_col];
+    float cnt = 0.f;
+    for (int tt = lane; tt < T_len; tt += 64) cnt += ids[b * T_len + tt] >= 0 ? 1.f : 0.f;
+    float st = 0.f;
+    if (mask)
+        for (int c = lane; c < V; c += 64)
+            st += ElemTraits<T>::load(yhat, (int64_t)m * kp + c) * ElemTraits<T>::load(w, (int64_t)id * kp + c);
+    cnt = wave_sum(cnt);
+    st = wave_sum(st);
+    const float p_t = exp2f(st) / sumexp;
+    const bool live = mask && p_t > 1e-7f && p_t < (1.0f - 1e-7f);
+    const float p_c = fminf(fmaxf(p_t, 1e-7f), 1.0f - 1e-7f);
+    if (lane == 0) xent_rows[m] = mask ? -logf(p_c) : 0.0f;
+    if (dy.data == nullptr) return;
+    const float coef = live ? inv_tau_eff / (cnt * (float)B_global) : 0.0f;
+    const float inv_se = 1.0f / sumexp;
+    const int64_t drow = (int64_t)b * dy.bstride + (int64_t)(dy.off + t) * dy.cp;
+    if (coef == 0.0f) {                                          // masked / clipped row: zero gradient (wave-uniform branch)
+        for (int c = lane; c < V; c += 64) store_any(dy.data, dy.dtype, drow + c, 0.0f);
+        return;
+    }
+    // u (summed over splits), yhat and the target row stay in registers between the two passes (V <= 64*UC)
+    constexpr int UC = 8;
+    float uu[UC], yy[UC];
+    float dot = 0.f;
+    if (V <= 64 * UC) {
+#pragma unroll
+        for (int k = 0; k < UC; ++k) {
+            const int c = lane + 64 * k;
+            uu[k] = 0.f; yy[k] = 0.f;
+            if (c < V) {
+                float u = 0.f;
+                for (int sp = 0; sp < splits; ++sp) u += ut[((int64_t)sp * m_pad + m) * kp + c];
+                uu[k] = coef * (u * inv_se - ElemTraits<T>::load(w, (int64_t)id * kp + c));
+                yy[k] = ElemTraits<T>::load(yhat, (int64_t)m * kp + c) * inv_q;
+                dot += uu[k] * yy[k];
+            }
         }
         dot = wave_sum(dot);
         const float rn = rnorm[m];
         const bool normal = rn < 0.99e6f;                       // sum y^2 >= 1e-12
-        for (int c = lane; c < V; c += 64) {
-            const float wt = id >= 0 ? ElemTraits<T>::load(w, (int64_t)id * kp + c) : 0.f;
-            const float dyh = coef * (ur[c] * inv_se - wt);
-            const float yh = ElemTraits<T>::load(yhat, (int64_t)m * kp + c) * inv_q;
-            const float g = normal ? (dyh - yh * dot) * rn : dyh * rn;
-            store_any(dy.data, dy.dtype, (int64_t)b * dy.bstride + (int64_t)(dy.off + t) * dy.cp + c, g);
+#pragma unroll
+        for (int k = 0; k < UC; ++k) {
+            const int c = lane + 64 * k;
+            if (c < V) store_any(dy.data, dy.dtype, drow + c, normal ? (uu[k] - yy[k] * dot) * rn : uu[k] * rn);
         }
+        return;
+    }
+    for (int c = lane; c < V; c += 64) {
+        float u = 0.f;
+        for (int sp = 0; sp < splits; ++sp) u += ut[((int64_t)sp * m_pad + m) * kp + c];
+        const float dyh = coef * (u * inv_se - ElemTraits<T>::load(w, (int64_t)id * kp + c));
+        dot += dyh * ElemTraits<T>::load(yhat, (int64_t)m * kp + c) * inv_q;
+    }
+    dot = wave_sum(dot);
+    const float rn = rnorm[m];
+    const bool normal = rn < 0.99e6f;                           // sum y^2 >= 1e-12
+    for (int c = lane; c < V; c += 64) {
+        float u = 0.f;
+        for (int sp = 0; sp < splits; ++sp) u += ut[((int64_t)sp * m_pad + m) * kp + c];
+        const float dyh = coef * (u * inv_se - ElemTraits<T>::load(w, (int64_t)id * kp + c));
+        const float yh = ElemTraits<T>::load(yhat, (int64_t)m * kp + c) * inv_q;
+        store_any(dy.data, dy.dtype, drow + c, normal ? (dyh - yh * dot) * rn : dyh * rn);
     }
 }
 
 // loss scalars (single block, deterministic order)
-__global__ __launch_bounds__(256) void loss_reduce_kernel(const float* __restrict__ xent_rows, const int* __restrict__ ids,
-                                                          const float* __restrict__ kl_b, int B, int T_len, int B_global,
-                                                          float* __restrict__ out3, float* __restrict__ xent_b) {
-    __shared__ float sx[256], sk[256];
+__global__ __launch_bounds__(1024) void loss_reduce_kernel(const float* __restrict__ xent_rows, const int* __restrict__ ids,
+                                                           const float* __restrict__ kl_b, int B, int T_len, int B_global,
+                                                           float* __restrict__ out3, float* __restrict__ xent_b) {
+    // 16 waves; wave w owns samples w, w+16, ...; lanes run over the steps of a sample (coalesced); every sum has a fixed order
+    __shared__ float sx[16], sk[16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float ax = 0.f, ak = 0.f;
-    for (int b = threadIdx.x; b < B; b += 256) {
+    for (int b = wave; b < B; b += 16) {
         float s = 0.f, c = 0.f;
-        for (int t = 0; t < T_len; ++t) { s += xent_rows[b * T_len + t]; c += ids[b * T_len + t] >= 0 ? 1.f : 0.f; }
+        for (int t = lane; t < T_len; t += 64) { s += xent_rows[b * T_len + t]; c += ids[b * T_len + t] >= 0 ? 1.f : 0.f; }
+        s = wave_sum(s); c = wave_sum(c);
         const float xb = s / c;
-        if (xent_b) xent_b[b] = xb;
+        if (lane == 0 && xent_b) xent_b[b] = xb;
         ax += xb;
         ak += kl_b ? kl_b[b] : 0.f;
     }
-    sx[threadIdx.x] = ax; sk[threadIdx.x] = ak;
+    if (lane == 0) { sx[wave] = ax; sk[wave] = ak; }
     __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if (threadIdx.x < o) { sx[threadIdx.x] += sx[threadIdx.x + o]; sk[threadIdx.x] += sk[threadIdx.x + o]; }
-        __syncthreads();
-    }
     if (threadIdx.x == 0) {
+        float tx = 0.f, tk = 0.f;
+        for (int i = 0; i < 16; ++i) { tx += sx[i]; tk += sk[i]; }
         const float inv = 1.0f / (float)B_global;
-        out3[0] = (sx[0] - sk[0]) * inv; out3[1] = sx[0] * inv; out3[2] = sk[0] * inv;
+        out3[0] = (tx - tk) * inv; out3[1] = tx * inv; out3[2] = tk * inv;
     }
 }
 
@@ -416,6 +442,10 @@ static int xent_accum_unfused(const c1v_xent_accum_args* a, hipStream_t st) {
         e.act_rowmul = 1; e.M = ncount; e.Le = 1; e.nrows = 1; e.N = a->M;
         int rc = c1v_launch_nt(a->dtype, p, st);
         if (rc) return rc;
+        if (chunks > 1 && ncount < a->n_chunk) {   // rows of the tile that straddles the end still hold the previous chunk
+            const int64_t tail = c1v_cdiv(ncount, 64) * 64 - ncount;
+            if (tail > 0) (void)hipMemsetAsync((char*)a->logits + (int64_t)ncount * a->m_pad * es, 0, (size_t)tail * a->m_pad * es, st);
+        }
         if (!a->need_u) {
             // only the denominator: column sums of E over n  == row `ones_col` of U^T
             TnParams t{};
@@ -423,15 +453,15 @@ static int xent_accum_unfused(const c1v_xent_accum_args* a, hipStream_t st) {
             t.I = a->ones_col % 128 + 1; t.Ia = (a->kp - a->ones_col / 128 * 128) < 128 ? (a->kp - a->ones_col / 128 * 128) : 128;
             t.D = (const char*)a->logits; t.ldd_b = (int64_t)a->m_pad * es; t.J = a->M; t.Ja = a->m_pad;
             t.r_begin = 0; t.r_end = ncount; t.rows_per_split = c1v_cdiv(ncount, spc);
-            t.a_shift0 = 0; t.taps = 1; t.flip = 0; t.tap_stride = 0; t.si = a->m_pad; t.sj = 1;
-            t.out = a->ut + ((int64_t)ch * spc * a->kp + (a->ones_col / 128 * 128)) * a->m_pad; t.slab_stride = (int64_t)a->kp * a->m_pad; t.splits = spc;
+            t.a_shift0 = 0; t.taps = 1; t.flip = 0; t.tap_stride = 0; t.si = 1; t.sj = a->kp;
+            t.out = a->ut + (int64_t)ch * spc * a->kp * a->m_pad + (a->ones_col / 128 * 128); t.slab_stride = (int64_t)a->kp * a->m_pad; t.splits = spc;
             rc = c1v_launch_tn(a->dtype, t, st);
         } else {
             TnParams t{};
             t.A = (const char*)a->w + (int64_t)nc0 * a->kp * es; t.lda_b = (int64_t)a->kp * es; t.I = a->kp; t.Ia = a->kp;
             t.D = (const char*)a->logits; t.ldd_b = (int64_t)a->m_pad * es; t.J = a->M; t.Ja = a->m_pad;
             t.r_begin = 0; t.r_end = ncount; t.rows_per_split = c1v_cdiv(ncount, spc);
-            t.a_shift0 = 0; t.taps = 1; t.flip = 0; t.tap_stride = 0; t.si = a->m_pad; t.sj = 1;
+            t.a_shift0 = 0; t.taps = 1; t.flip = 0; t.tap_stride = 0; t.si = 1; t.sj = a->kp;
             t.out = a->ut + (int64_t)ch * spc * a->kp * a->m_pad; t.slab_stride = (int64_t)a->kp * a->m_pad; t.splits = spc;
             rc = c1v_launch_tn(a->dtype, t, st);
         }
@@ -470,8 +500,8 @@ extern "C" int c1v_cos_softmax_finish(const c1v_xent_finish_args* a, void* strea
     C1V_REQUIRE(a->m_pad >= (int)(c1v_cdiv((int64_t)a->B * a->T, 32) * 32), "cos_softmax_finish: m_pad too small");
     C1V_REQUIRE(a->dy.data == nullptr || (a->dy.cp >= a->V && a->dy.len >= a->T), "cos_softmax_finish: dy buffer too small");
     const int M = a->B * a->T;
-    const size_t lds = (size_t)32 * (a->kp + 1) * sizeof(float);
-    dim3 grid((unsigned)c1v_cdiv(M, 32));
+    const size_t lds = 0;
+    dim3 grid((unsigned)c1v_cdiv(M, 4));
     if (a->dtype == C1V_F32)
         hipLaunchKernelGGL(xent_finish_kernel<float>, grid, dim3(256), lds, (hipStream_t)stream, a->ut, a->splits, a->kp, a->m_pad, a->ones_col,
                            (const float*)a->yhat, (const float*)a->w, a->rnorm, a->qscale, a->ids, a->B, a->T, a->V, a->B_global, a->xent_rows, a->dy);
@@ -485,7 +515,7 @@ extern "C" int c1v_cos_softmax_finish(const c1v_xent_finish_args* a, void* strea
 extern "C" int c1v_loss_reduce(const float* xent_rows, const int32_t* ids, const float* kl_b, int32_t B, int32_t T, int32_t B_global,
                                float* out3, float* xent_b, void* stream) {
     C1V_REQUIRE(xent_rows && ids && out3 && B > 0 && T > 0 && B_global > 0, "loss_reduce: bad argument");
-    hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, xent_rows, ids, kl_b, B, T, B_global, out3, xent_b);
+    hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, xent_rows, ids, kl_b, B, T, B_global, out3, xent_b);
     C1V_LAUNCH_CHECK();
     return 0;
 }

@@ -133,26 +133,27 @@ class VAEEngine:
             c_in = geom.n_filters[l]
         F_last = geom.n_filters[-1]
         self.flat = geom.flat_size
-        self.flat_p = _pad(self.flat, 32)
-        self.H = Buf(z(B * self.flat_p + 64, dt=self.tdt), B, self.flat_p, 0, geom.enc_len_pool[-1], F_last, F_last)
+        self.flat_p = _pad(self.flat, 64)
+        RS = L.SLACK_ROWS                                   # zero rows behind every GEMM operand (unpredicated tile loads)
+        self.H = Buf(z((B + RS) * self.flat_p, dt=self.tdt), B, self.flat_p, 0, geom.enc_len_pool[-1], F_last, F_last)
         D = geom.latent_dim
         self.D = D
-        self.Dp = _pad(D, 32)
-        self.D2p = _pad(2 * D, 32)
+        self.Dp = _pad(D, 64)
+        self.D2p = _pad(2 * D, 64)
         self.mlv = z(B, 2 * D)
         self.eps = z(B, D)
         self.eps_zero = z(B, D)
         self.keep_e = torch.ones(B, self.flat, dtype=torch.uint8, device=self.dev)
         self.keep_d = torch.ones(B, D, dtype=torch.uint8, device=self.dev)
-        self.zd = z(B * self.Dp + 64, dt=self.tdt)
+        self.zd = z((B + RS) * self.Dp, dt=self.tdt)
         self.z_out = z(B, D)
         self.kl_b = z(B)
         self.dzd = z(B, D)
-        self.dmlv = z(B * self.D2p + 64, dt=self.tdt)
+        self.dmlv = z((B + RS) * self.D2p, dt=self.tdt)
         nd = geom.n_times * geom.width
         self.nd = nd
-        self.nd_p = _pad(nd, 32)
-        self.dDense = Buf(z(B * self.nd_p + 64, dt=self.tdt), B, self.nd_p, 0, geom.n_times, geom.width, geom.width)
+        self.nd_p = _pad(nd, 64)
+        self.dDense = Buf(z((B + RS) * self.nd_p, dt=self.tdt), B, self.nd_p, 0, geom.n_times, geom.width, geom.width)
         self.Xd: List[Buf] = []
         self.dOd: List[Buf] = []
         c_in = geom.width
@@ -174,10 +175,10 @@ class VAEEngine:
         # ---------------- loss
         self.M = B * To
         self.m_pad = _pad(self.M, 128)
-        self.kp = _pad(self.V + 1, 32)               # at least one spare column: `ones_col` carries the softmax denominator
+        self.kp = _pad(self.V + 1, 64)               # at least one spare column: `ones_col` carries the softmax denominator
         self.ones_col = self.V
         self.qscale = LOG2E / TAU
-        self.yhat = z(self.m_pad * self.kp, dt=self.tdt)
+        self.yhat = z((self.m_pad + RS) * self.kp, dt=self.tdt)
         self.rnorm = z(self.m_pad)
         self.xent_rows = z(self.m_pad)
         self.xent_b = z(B)
@@ -237,7 +238,7 @@ class VAEEngine:
             raise ValueError('vocabulary matrix must be [N, {0}]'.format(self.V))
         self.N = W.shape[0]
         self.n_pad = _pad(self.N, 64)
-        host = np.zeros((self.n_pad, self.kp), dtype=np.float32)
+        host = np.zeros((self.n_pad + L.SLACK_ROWS, self.kp), dtype=np.float32)
         host[:self.N, :self.V] = W
         host[:self.N, self.ones_col] = 1.0
         self.w_vocab = torch.from_numpy(host).to(self.dev).to(self.tdt).contiguous()
@@ -249,11 +250,11 @@ class VAEEngine:
             self.n_chunk = 0
             self.logits = None
         else:
-            self.n_chunk = int(min(self.n_pad, max(1024, (1 << 28) // self.m_pad)))
+            self.n_chunk = int(min(self.n_pad, max(1024, (1 << 28) // self.m_pad // 64 * 64)))
             chunks = (self.N + self.n_chunk - 1) // self.n_chunk
             spc = 8 if self.n_chunk >= 2048 else 1
             self.x_splits = chunks * spc
-            self.logits = torch.zeros(self.n_chunk * self.m_pad, dtype=self.tdt, device=self.dev)
+            self.logits = torch.zeros((self.n_chunk + L.SLACK_ROWS) * self.m_pad, dtype=self.tdt, device=self.dev)
         self.ut = torch.zeros(self.x_splits * self.kp * self.m_pad, dtype=torch.float32, device=self.dev)
         if hasattr(self, '_ops_built'):
             self._build_ops()
@@ -269,12 +270,17 @@ class VAEEngine:
         descs: List[L.PackDesc] = []
         self.wop: Dict[str, torch.Tensor] = {}
 
+        self.wld: Dict[str, int] = {}
+        nblk = [0]
+
         def add(key, src_name, n_count, taps, c_count, cp, flip, s_tap, s_c, s_n):
-            ldk = taps * cp
-            t = torch.zeros(n_count * ldk + 64, dtype=self.tdt, device=self.dev)
+            ldk = _pad(taps * cp, 64)                      # rows zero-padded to whole 128-byte K tiles
+            t = torch.zeros((n_count + 1) * ldk, dtype=self.tdt, device=self.dev)
             self.wop[key] = t
+            self.wld[key] = ldk
             descs.append(L.PackDesc(self._pslice(src_name), t.data_ptr(), self.code, n_count, taps, c_count, cp, flip,
-                                    ldk, s_tap, s_c, s_n))
+                                    ldk, s_tap, s_c, s_n, nblk[0], 0))
+            nblk[0] += (n_count * taps * c_count + L.CHUNK - 1) // L.CHUNK
 
         c_in = g.input_vector_size
         for l, f in enumerate(g.n_filters):
@@ -301,10 +307,10 @@ class VAEEngine:
         arr = (L.PackDesc * len(descs))(*descs)
         self.pack_descs = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.dev)
         self.n_pack = len(descs)
-        self.pack_max = max(d.n_count * d.taps * d.c_count for d in descs)
+        self.pack_blocks = nblk[0]
 
         def pack_all():
-            L.call('c1v_pack_weights', self.pack_descs.data_ptr(), self.n_pack, self.pack_max, self._stream())
+            L.call('c1v_pack_weights', self.pack_descs.data_ptr(), self.n_pack, self.pack_blocks, self._stream())
         self._pack_all = pack_all
         pack_all()
 
@@ -356,11 +362,11 @@ class VAEEngine:
                               sel=self.sel[l].data_ptr(), sel_bstride=g.enc_len_pool[l] * F, sel_cp=F,
                               keep=keep, keep_scale=1.0 / KEEP_PROB)
                 ops.append(op('c1v_conv1d_fwd', L.ConvArgs(self.Xe[l].seq(), 0, g.enc_len_conv[l], k,
-                                                           self.wop['enc%d_fwd' % l].data_ptr(), F, e)))
+                                                           self.wop['enc%d_fwd' % l].data_ptr(), self.wld['enc%d_fwd' % l], F, e)))
             mlv_seq = L.Seq(self.mlv.data_ptr(), L.F32, B, 2 * self.D, 0, 1, 2 * self.D, 2 * self.D)
             e = self._epi(mlv_seq, L.ROW_STORE, self._bias_ptr('z_heads/bias'))
             ops.append(op('c1v_dense_fwd', L.DenseArgs(self.H.t.data_ptr(), self.code, B, self.flat_p, self.flat_p,
-                                                       self.wop['heads_fwd'].data_ptr(), self.flat_p, 2 * self.D, e)))
+                                                       self.wop['heads_fwd'].data_ptr(), self.wld['heads_fwd'], 2 * self.D, e)))
             return ops
 
         def latent(train: bool, sample: bool):
@@ -378,7 +384,7 @@ class VAEEngine:
             ops = []
             e = self._epi(self.Xd[0].seq(), L.ROW_STORE, self._bias_ptr('deconv_decoder_dense/bias'), 1, reshape_w=g.width)
             ops.append(op('c1v_dense_fwd', L.DenseArgs(self.zd.data_ptr(), self.code, B, self.Dp, self.Dp,
-                                                       self.wop['dense_fwd'].data_ptr(), self.Dp, self.nd, e)))
+                                                       self.wop['dense_fwd'].data_ptr(), self.wld['dense_fwd'], self.nd, e)))
             for i in range(nd):
                 last = i == nd - 1
                 dstb = self.Xf if last else self.Xd[i + 1]
@@ -386,10 +392,11 @@ class VAEEngine:
                 e = self._epi(dstb.seq(length=dst_len), L.ROW_UP2,
                               self._bias_ptr('deconv_decoder_%d_deconv1d_part2/bias' % (i + 1)), 1)
                 ops.append(op('c1v_deconv1d_fwd', L.ConvArgs(self.Xd[i].seq(), 0, g.dec_len_deconv[i], k,
-                                                             self.wop['dec%d_fwd' % i].data_ptr(), g.dec_filters[i], e)))
+                                                             self.wop['dec%d_fwd' % i].data_ptr(), self.wld['dec%d_fwd' % i],
+                                                             g.dec_filters[i], e)))
             e = self._epi(self.Y.seq(), L.ROW_STORE, self._bias_ptr('deconv_decoder_embeddings/bias'))
             ops.append(op('c1v_conv1d_fwd', L.ConvArgs(self.Xf.seq(), 0, g.output_text_size, k,
-                                                       self.wop['out_fwd'].data_ptr(), self.V, e)))
+                                                       self.wop['out_fwd'].data_ptr(), self.wld['out_fwd'], self.V, e)))
             return ops
 
         self.ops_enc_train = enc_fwd(True)
@@ -428,21 +435,24 @@ class VAEEngine:
                 L.check(f_red(self.xent_rows.data_ptr(), self.ids_in.data_ptr(), self.kl_b.data_ptr(), B,
                               g.output_text_size, self.Bg, self.loss_out.data_ptr(), self.xent_b.data_ptr(),
                               self._stream()), 'c1v_loss_reduce')
-            ops.append(red)
-            return ops
+            return ops, red
 
-        self.ops_loss_train = loss_ops(True)
-        self.ops_loss_eval = loss_ops(False)
+        self.ops_loss_train, self.op_loss_reduce = loss_ops(True)
+        self.ops_loss_eval, red_eval = loss_ops(False)
+        self.ops_loss_eval = self.ops_loss_eval + [red_eval]
 
         # ---- backward
         segs: List[L.SegDesc] = []
         self.slabs: Dict[str, torch.Tensor] = {}
 
+        fblk = [0]
+
         def slab(name: str, splits: int, frozen=False):
             count = int(np.prod(self.seg_shapes[name]))
             t = torch.zeros(splits * count, dtype=torch.float32, device=self.dev)
             self.slabs[name] = t
-            segs.append(L.SegDesc(t.data_ptr(), count, splits, 1, 0, self.seg_off[name], count, 1 if frozen else 0, 0))
+            segs.append(L.SegDesc(t.data_ptr(), count, splits, 1, 0, self.seg_off[name], count, 1 if frozen else 0, fblk[0]))
+            fblk[0] += (count + L.CHUNK - 1) // L.CHUNK
             return t
 
         def row_splits(rows: int) -> int:
@@ -458,8 +468,7 @@ class VAEEngine:
             if not frozen:
                 ops.append(op('c1v_conv1d_wgrad', L.WgradArgs(X.t.data_ptr(), X.cp, C_in, dO.t.data_ptr(), dO.cp, F,
                                                               self.code, k - 1, rows, -(k - 1), k, flip, tap_stride, si, sj,
-                                                              wt.data_ptr(), count, sp)))
-                ops.append(op('c1v_colsum', L.ColsumArgs(dO.t.data_ptr(), self.code, rows, dO.cp, F, bt.data_ptr(), F, sp)))
+                                                              wt.data_ptr(), count, sp, bt.data_ptr(), F)))
             return ops
 
         def dense_wgrad(a_ptr, lda, I, d_ptr, ldd, J, wname, bname, frozen=False):
@@ -468,99 +477,114 @@ class VAEEngine:
             ops = []
             if not frozen:
                 ops.append(op('c1v_dense_wgrad', L.WgradArgs(a_ptr, lda, I, d_ptr, ldd, J, self.code, 0, B, 0, 1, 0, 0, J, 1,
-                                                             wt.data_ptr(), I * J, 1)))
-                ops.append(op('c1v_colsum', L.ColsumArgs(d_ptr, self.code, B, ldd, J, bt.data_ptr(), J, 1)))
+                                                             wt.data_ptr(), I * J, 1, bt.data_ptr(), J)))
             return ops
 
-        bwd = []
-        # segments must be registered in flat-buffer order for readability only; order of ops is the backward order
+        # Backward as stages: in each stage the dgrad chain continues on the main stream while the wgrad of the same
+        # layer (it only needs the stage's dO buffer) runs on a side stream; the captured graph keeps both branches.
+        stages = []           # (main ops, side ops); side ops may start when the previous stage's main ops are done
         C_last = g.dec_filters[-1]
-        bwd += conv_wgrad(self.Xf, self.dOf, 'deconv_decoder_embeddings/kernel', 'deconv_decoder_embeddings/bias',
-                          C_last, self.V, 0, C_last * self.V, self.V, 1)
+        side = [self.op_loss_reduce]
+        side += conv_wgrad(self.Xf, self.dOf, 'deconv_decoder_embeddings/kernel', 'deconv_decoder_embeddings/bias',
+                           C_last, self.V, 0, C_last * self.V, self.V, 1)
         e = self._epi(self.dOd[nd - 1].seq(), L.ROW_PAIRSUM, act=self.Xf.seq(), act_rowmul=2, act_scale=1.0)
-        bwd.append(op('c1v_conv1d_dgrad', L.ConvArgs(self.dOf.seq(), g.pad_left, g.output_text_size, k,
-                                                     self.wop['out_dg'].data_ptr(), C_last, e)))
+        main = [op('c1v_conv1d_dgrad', L.ConvArgs(self.dOf.seq(), g.pad_left, g.output_text_size, k,
+                                                  self.wop['out_dg'].data_ptr(), self.wld['out_dg'], C_last, e))]
+        stages.append((main, side))
         for i in reversed(range(nd)):
             C_in = g.width if i == 0 else g.dec_filters[i - 1]
             F = g.dec_filters[i]
             nm = 'deconv_decoder_%d_deconv1d_part2' % (i + 1)
-            bwd += conv_wgrad(self.Xd[i], self.dOd[i], nm + '/kernel', nm + '/bias', C_in, F, 1, F * C_in, 1, C_in)
+            side = conv_wgrad(self.Xd[i], self.dOd[i], nm + '/kernel', nm + '/bias', C_in, F, 1, F * C_in, 1, C_in)
             if i > 0:
                 e = self._epi(self.dOd[i - 1].seq(), L.ROW_PAIRSUM, act=self.Xd[i].seq(), act_rowmul=2, act_scale=1.0)
             else:
                 e = self._epi(self.dDense.seq(), L.ROW_STORE, act=self.Xd[0].seq(), act_rowmul=1, act_scale=1.0)
-            bwd.append(op('c1v_deconv1d_dgrad', L.ConvArgs(self.dOd[i].seq(), k - 1, g.dec_in_len[i], k,
-                                                           self.wop['dec%d_dg' % i].data_ptr(), C_in, e)))
-        bwd += dense_wgrad(self.zd.data_ptr(), self.Dp, self.D, self.dDense.t.data_ptr(), self.nd_p, self.nd,
+            main = [op('c1v_deconv1d_dgrad', L.ConvArgs(self.dOd[i].seq(), k - 1, g.dec_in_len[i], k,
+                                                        self.wop['dec%d_dg' % i].data_ptr(), self.wld['dec%d_dg' % i], C_in, e))]
+            stages.append((main, side))
+        side = dense_wgrad(self.zd.data_ptr(), self.Dp, self.D, self.dDense.t.data_ptr(), self.nd_p, self.nd,
                            'deconv_decoder_dense/kernel', 'deconv_decoder_dense/bias')
+        main = []
         if not self.frozen:
             dzd_seq = L.Seq(self.dzd.data_ptr(), L.F32, B, self.D, 0, 1, self.D, self.D)
-            bwd.append(op('c1v_dense_dgrad', L.DenseArgs(self.dDense.t.data_ptr(), self.code, B, self.nd_p, self.nd_p,
-                                                         self.wop['dense_dg'].data_ptr(), self.nd_p, self.D,
-                                                         self._epi(dzd_seq))))
-            bwd.append(op('c1v_latent_head_bwd', self._lat_train))
-        bwd += dense_wgrad(self.H.t.data_ptr(), self.flat_p, self.flat, self.dmlv.data_ptr(), self.D2p, 2 * self.D,
+            main.append(op('c1v_dense_dgrad', L.DenseArgs(self.dDense.t.data_ptr(), self.code, B, self.nd_p, self.nd_p,
+                                                          self.wop['dense_dg'].data_ptr(), self.wld['dense_dg'], self.D,
+                                                          self._epi(dzd_seq))))
+            main.append(op('c1v_latent_head_bwd', self._lat_train))
+        stages.append((main, side))
+        side = dense_wgrad(self.H.t.data_ptr(), self.flat_p, self.flat, self.dmlv.data_ptr(), self.D2p, 2 * self.D,
                            'z_heads/kernel', 'z_heads/bias', self.frozen)
+        main = []
         if not self.frozen:
             F = g.n_filters[-1]
             e = self._epi(self.dOe[nl - 1].seq(), L.ROW_UNPOOL, reshape_w=F, act=self.H.seq(), act_scale=1.0 / KEEP_PROB,
                           sel=self.sel[nl - 1].data_ptr(), sel_bstride=g.enc_len_pool[nl - 1] * F, sel_cp=F)
-            bwd.append(op('c1v_dense_dgrad', L.DenseArgs(self.dmlv.data_ptr(), self.code, B, self.D2p, self.D2p,
-                                                         self.wop['heads_dg'].data_ptr(), self.D2p, self.flat, e)))
+            main.append(op('c1v_dense_dgrad', L.DenseArgs(self.dmlv.data_ptr(), self.code, B, self.D2p, self.D2p,
+                                                          self.wop['heads_dg'].data_ptr(), self.wld['heads_dg'], self.flat, e)))
+        stages.append((main, side))
         for l in reversed(range(nl)):
             C_in = g.input_vector_size if l == 0 else g.n_filters[l - 1]
             F = g.n_filters[l]
             nm = 'encoder_conv1d_%d' % (l + 1)
-            bwd += conv_wgrad(self.Xe[l], self.dOe[l], nm + '/kernel', nm + '/bias', C_in, F, 0, C_in * F, F, 1, self.frozen)
+            side = conv_wgrad(self.Xe[l], self.dOe[l], nm + '/kernel', nm + '/bias', C_in, F, 0, C_in * F, F, 1, self.frozen)
+            main = []
             if l > 0 and not self.frozen:
                 Fp = g.n_filters[l - 1]
                 e = self._epi(self.dOe[l - 1].seq(), L.ROW_UNPOOL, act=self.Xe[l].seq(), act_scale=1.0,
                               sel=self.sel[l - 1].data_ptr(), sel_bstride=g.enc_len_pool[l - 1] * Fp, sel_cp=Fp)
-                bwd.append(op('c1v_conv1d_dgrad', L.ConvArgs(self.dOe[l].seq(), 0, g.enc_in_len[l], k,
-                                                             self.wop['enc%d_dg' % l].data_ptr(), Fp, e)))
-        self.ops_bwd = bwd
+                main.append(op('c1v_conv1d_dgrad', L.ConvArgs(self.dOe[l].seq(), 0, g.enc_in_len[l], k,
+                                                              self.wop['enc%d_dg' % l].data_ptr(), self.wld['enc%d_dg' % l], Fp, e)))
+            stages.append((main, side))
+        self.bwd_stages = stages
+        self.side_stream = torch.cuda.Stream(self.dev)
 
         # ---- optimizer
         arr = (L.SegDesc * len(segs))(*segs)
         self.seg_descs = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.dev)
         self.n_seg = len(segs)
-        self.seg_max = max(s.count for s in segs)
-        self.n_partial = int(self.lib.c1v_grad_finalize_partials(self.n_seg, self.seg_max))
-        self.sq_partial = torch.zeros(max(self.n_partial, 256), dtype=torch.float32, device=self.dev)
+        self.fin_blocks = fblk[0]
+        self.sq_partial = torch.zeros(max(self.fin_blocks, 256), dtype=torch.float32, device=self.dev)
         f_fin = self.lib.c1v_grad_finalize
         f_sq = self.lib.c1v_sqnorm_partial
         f_adv = self.lib.c1v_nadam_advance
+        n_partial = self.fin_blocks if self.world == 1 else 256
 
         def finalize():
-            L.check(f_fin(self.seg_descs.data_ptr(), self.n_seg, self.seg_max, self.grads.data_ptr(),
-                          self.sq_partial.data_ptr(), self.n_partial, self._stream()), 'c1v_grad_finalize')
+            L.check(f_fin(self.seg_descs.data_ptr(), self.n_seg, self.fin_blocks, self.grads.data_ptr(),
+                          self.sq_partial.data_ptr(), self._stream()), 'c1v_grad_finalize')
 
         def sqnorm():
             L.check(f_sq(self.grads.data_ptr(), self.P, self.sq_partial.data_ptr(), 256, self._stream()), 'c1v_sqnorm_partial')
 
         def advance():
-            L.check(f_adv(self.nadam_state.data_ptr(), self.sched.data_ptr(), self._stream()), 'c1v_nadam_advance')
+            L.check(f_adv(self.nadam_state.data_ptr(), self.sched.data_ptr(), self.sq_partial.data_ptr(), n_partial,
+                          self.step_ctr.data_ptr(), self._stream()), 'c1v_nadam_advance')
 
         self.ops_finalize = [finalize]
         nad = L.NadamArgs(self.params.data_ptr(), self.grads.data_ptr(), self.nadam_m.data_ptr(), self.nadam_v.data_ptr(),
-                          self.P, self.sq_partial.data_ptr(), self.n_partial if self.world == 1 else 256,
-                          1.0, CLIPNORM, self.sched.data_ptr(), 0.9, 0.999, 1e-7, self.norm_out.data_ptr())
+                          self.P, 1.0, CLIPNORM, self.sched.data_ptr(), 0.9, 0.999, 1e-7, self.norm_out.data_ptr())
         self.ops_update = ([] if self.world == 1 else [sqnorm]) + [advance, op('c1v_nadam_step', nad), self._pack_all]
 
-        # ---- RNG (device counter => replayable)
+        # ---- RNG (device counter => replayable): eps + both dropout masks in ONE launch; the counter advances in
+        # nadam_advance at the end of the step
+        thr = int(np.float32(KEEP_PROB) * np.float32(16777216.0))
+        reqs = [(self.eps.data_ptr(), B * self.D, 0, 0, 1, self.rank * B * self.D, self.Bg * self.D),
+                (self.keep_e.data_ptr(), B * self.flat, 1, thr, 2, self.rank * B * self.flat, self.Bg * self.flat),
+                (self.keep_d.data_ptr(), B * self.D, 1, thr, 3, self.rank * B * self.D, self.Bg * self.D)]
+        rd, nb = [], 0
+        for (ptr, n, kind, th, sid, off, mul) in reqs:
+            rd.append(L.RngDesc(ptr, n, kind, th, sid, off, mul, nb, 0))
+            nb += (n + 3 + 1023) // 1024 + 1
+        arr = (L.RngDesc * len(rd))(*rd)
+        self.rng_descs = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.dev)
+        f_m = self.lib.c1v_philox_multi
         f_n = self.lib.c1v_philox_normal
-        f_b = self.lib.c1v_philox_bernoulli
         f_c = self.lib.c1v_counter_add
+        n_rd, rng_blocks = len(rd), nb
 
         def rng():
-            st = self._stream()
-            ctr = self.step_ctr.data_ptr()
-            L.check(f_n(self.eps.data_ptr(), B * self.D, self.seed, 1, self.rank * B * self.D, ctr, self.Bg * self.D, st), 'philox')
-            L.check(f_b(self.keep_e.data_ptr(), B * self.flat, KEEP_PROB, self.seed, 2, self.rank * B * self.flat, ctr,
-                        self.Bg * self.flat, st), 'philox')
-            L.check(f_b(self.keep_d.data_ptr(), B * self.D, KEEP_PROB, self.seed, 3, self.rank * B * self.D, ctr,
-                        self.Bg * self.D, st), 'philox')
-            L.check(f_c(ctr, 1, st), 'counter_add')
+            L.check(f_m(self.rng_descs.data_ptr(), n_rd, rng_blocks, self.seed, self.step_ctr.data_ptr(), self._stream()), 'philox_multi')
 
         def rng_eval():
             st = self._stream()
@@ -613,10 +637,24 @@ class VAEEngine:
         if ids is not None:
             self.ids_in.copy_(torch.as_tensor(ids, dtype=torch.int32), non_blocking=True)
 
+    def _run_backward(self):
+        """dgrad chain on the current stream, wgrads (and the loss scalars) on the side stream; joined at the end."""
+        main = torch.cuda.current_stream(self.dev)
+        side = self.side_stream
+        for main_ops, side_ops in self.bwd_stages:
+            if side_ops:
+                ev = torch.cuda.Event()
+                ev.record(main)
+                side.wait_event(ev)
+                with torch.cuda.stream(side):
+                    self._run(side_ops)
+            self._run(main_ops)
+        main.wait_stream(side)
+
     def train_ops(self, with_rng: bool):
-        ops = (self.ops_rng if with_rng else []) + self.ops_pack_in + self.ops_enc_train + self.ops_lat_train + \
-            self.ops_dec + self.ops_loss_train + self.ops_bwd + self.ops_finalize
-        return ops
+        fwd = (self.ops_rng if with_rng else []) + self.ops_pack_in + self.ops_enc_train + self.ops_lat_train + \
+            self.ops_dec + self.ops_loss_train
+        return fwd + [self._run_backward] + self.ops_finalize
 
     def train_step(self, use_graph: bool = True, fixed_rng: bool = False, all_reduce=None):
         """One fit step on the batch resident in x_in / ids_in: forward, loss, backward, clip, Nadam, operand refresh.
@@ -696,15 +734,15 @@ class VocabDecoder:
         self.code = L.BF16 if dtype == 'bf16' else L.F32
         W = np.asarray(vocab_norm, dtype=np.float32)
         self.N, self.K = W.shape
-        self.kp = _pad(self.K, 32)
+        self.kp = 32 if self.K <= 32 else _pad(self.K, 64)
         self.n_pad = _pad(self.N, 64)
         self.n_base = int(n_base)
-        host = np.zeros((self.n_pad, self.kp), dtype=np.float32)
+        host = np.zeros((self.n_pad + L.SLACK_ROWS, self.kp), dtype=np.float32)
         host[:self.N, :self.K] = W
         self.w = torch.from_numpy(host).to(self.dev).to(self.tdt).contiguous()
         self.Mmax = int(max_queries)
         self.m_pad = _pad(self.Mmax, 128)
-        self.q = torch.zeros(self.m_pad * self.kp, dtype=self.tdt, device=self.dev)
+        self.q = torch.zeros((self.m_pad + L.SLACK_ROWS) * self.kp, dtype=self.tdt, device=self.dev)
         fused = self.code == L.BF16 and self.kp in (32, 64, 320)
         tiles = self.n_pad // 64
         self.splits = max(1, min(tiles, (2 * 256) // max(1, self.m_pad // 128), 16)) if fused else 1
@@ -715,7 +753,7 @@ class VocabDecoder:
         if fused:
             self.n_chunk, self.logits = 0, None
         else:
-            self.n_chunk = int(min(self.n_pad, max(1024, (1 << 28) // self.m_pad)))
+            self.n_chunk = int(min(self.n_pad, max(1024, (1 << 28) // self.m_pad // 64 * 64)))
             self.logits = torch.zeros(self.m_pad * self.n_chunk, dtype=torch.float32, device=self.dev)
 
     def load_queries(self, q: torch.Tensor):
@@ -723,7 +761,7 @@ class VocabDecoder:
         M = q.shape[0]
         if M > self.Mmax or q.shape[1] != self.K:
             raise ValueError('queries must be [<= {0}, {1}]'.format(self.Mmax, self.K))
-        qv = self.q.view(self.m_pad, self.kp)
+        qv = self.q[: self.m_pad * self.kp].view(self.m_pad, self.kp)
         qv[:M, :self.K].copy_(q.to(self.dev))
         self.M = M
 

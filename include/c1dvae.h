@@ -29,7 +29,9 @@ extern "C" {
 /* Channels-last padded sequence buffer.  Element (b, t, c) lives at
  *     data[b * bstride + (off + t) * cp + c]          (element units of `dtype`)
  * Rows outside [off, off+len) of a sample and channels >= c are kept ZERO by every producer; the
- * allocation carries `C1V_SLACK_ROWS` zero rows after the last sample so that window reads may run over. */
+ * allocation carries `C1V_SLACK_ROWS` zero rows after the last sample so that window reads and the unpredicated
+ * tile loads of the GEMM kernels (up to one 64-row tile) may run over.  No load in the GEMM kernels is predicated:
+ * K tails rely on the zero padding of the weight operand rows, row tails on these zero rows. */
 typedef struct c1v_seq {
     void*   data;
     int32_t dtype;
@@ -41,7 +43,7 @@ typedef struct c1v_seq {
     int32_t c;         /* valid channels */
 } c1v_seq;
 
-#define C1V_SLACK_ROWS 8
+#define C1V_SLACK_ROWS 72
 
 /* row modes of the fused epilogue */
 #define C1V_ROW_STORE   0   /* dst row = u                                                    */
@@ -85,6 +87,7 @@ typedef struct c1v_conv1d_args {
     int32_t      n_rows;      /* output rows per sample */
     int32_t      k;
     const void*  w_op;
+    int64_t      ldw;         /* row stride of w_op in elements: >= k*x.cp, rows zero-padded to whole 128-byte K tiles */
     int32_t      n_out;       /* valid output channels N */
     c1v_epilogue epi;
 } c1v_conv1d_args;
@@ -94,7 +97,8 @@ int c1v_deconv1d_fwd(const c1v_conv1d_args*, void* stream);     /* requires x.of
 int c1v_deconv1d_dgrad(const c1v_conv1d_args*, void* stream);
 
 /* ---- a3 / a5: Dense forward / dgrad (:1244-1245, :1253) -------------------------------------------------
- * out(b,n) = sum_k A[b*lda + k] * w_op[n][k], k < K (K multiple of 8 elements, rows 16-byte aligned). */
+ * out(b,n) = sum_k A[b*lda + k] * w_op[n][k], k < K (K multiple of 8 elements, rows 16-byte aligned; both operands
+ * readable up to the next multiple of 128 bytes of K, w_op zero there; A readable for 64 rows past `rows` in wgrad). */
 typedef struct c1v_dense_args {
     const void*  a;
     int32_t      dtype;
@@ -126,6 +130,8 @@ typedef struct c1v_wgrad_args {
     float*      out;
     int64_t     slab_stride;
     int32_t     splits;
+    float*      bias_out;        /* optional: bias_out[s*bias_slab_stride + j] = sum_{r in split s} D[r*ldd + j] (bias gradient) */
+    int64_t     bias_slab_stride;
 } c1v_wgrad_args;
 int c1v_wgrad(const c1v_wgrad_args*, void* stream);
 int c1v_conv1d_wgrad(const c1v_wgrad_args*, void* stream);
@@ -146,9 +152,11 @@ typedef struct c1v_pack_desc {
     const float* src; void* dst; int32_t dtype;
     int32_t n_count, taps, c_count, cp, flip;
     int64_t ldk, s_tap, s_c, s_n;
+    int32_t first_block, pad;   /* descriptor i owns blocks [first_block_i, first_block_{i+1}): ceil(elements / C1V_CHUNK) each */
 } c1v_pack_desc;
-/* `descs` is a DEVICE array of n_desc descriptors; max_elems = max over descs of n_count*taps*c_count */
-int c1v_pack_weights(const c1v_pack_desc* descs, int32_t n_desc, int64_t max_elems, void* stream);
+#define C1V_CHUNK 2048          /* elements handled by one block of the descriptor-table kernels */
+/* `descs` is a DEVICE array of n_desc descriptors (ascending first_block); total_blocks = sum of their block counts */
+int c1v_pack_weights(const c1v_pack_desc* descs, int32_t n_desc, int32_t total_blocks, void* stream);
 
 /* input featuriser output -> operand buffer: dst(b,t,c) = src[(b*T + t)*C + c] (float32 -> T, zero padded) */
 typedef struct c1v_pack_input_args { const float* src; int32_t T, C; c1v_seq dst; } c1v_pack_input_args;
@@ -182,7 +190,7 @@ int c1v_latent_head_bwd(const c1v_latent_args*, void* stream);
 /* ---- a8: cosine-softmax cross-entropy against the vocabulary matrix (:1193-1203, :1319, :1326) --------------
  * Step 1  c1v_l2norm_rows: yhat = y / sqrt(max(sum y^2, 1e-12)) * qscale  -> T [M][kp] (zero padded), rnorm[M]
  * Step 2  c1v_cos_softmax_accum: for every row m and vocabulary row n:  e = exp2(yhat_m . w_n)   (qscale = log2(e)/tau)
- *           UT[s][c][m] = sum_{n in split s} e * w_n[c]   (c < kp; column `ones_col` of w holds 1.0 => UT[.][ones_col][m] = sum e)
+ *           UT[s][m][c] = sum_{n in split s} e * w_n[c]   (c < kp; column `ones_col` of w holds 1.0 => UT[.][m][ones_col] = sum e)
  *         bf16: one fused MFMA kernel that never materialises the [M,N] logits; f32: NT GEMM + exp + TN GEMM
  *         through the caller's scratch `logits` ([n_chunk][m_pad] f32).
  * Step 3  c1v_cos_softmax_finish: per row: p_t, clip, xent, mask; per sample loss; dy = d loss / d y (T, padded conv-operand layout)
@@ -199,7 +207,7 @@ typedef struct c1v_xent_accum_args {
     const void* yhat; int32_t dtype; int32_t M, kp;
     const void* w;    /* [n_pad][kp] T, rows >= N zero, column ones_col = 1.0 on rows < N */
     int32_t N, n_pad;
-    float* ut;        /* [splits][kp][m_pad] f32 */
+    float* ut;        /* [splits][m_pad][kp] f32 */
     int32_t m_pad, splits;
     int32_t need_u;   /* 0: only the sum-exp row `ones_col` is produced (validation loss) */
     int32_t ones_col;
@@ -233,25 +241,24 @@ int c1v_loss_reduce(const float* xent_rows, const int32_t* ids, const float* kl_
  * c1v_grad_finalize: grad[seg.offset + i] = sum_{s<splits} sum_{r<reps} slab[s*slab_stride + r*rep_stride + i]
  *                    and sq_partial[block] = partial sum of grad^2 (when sq_partial != NULL)
  * c1v_sqnorm_partial: partial sums of squares of an arbitrary f32 buffer (after an all-reduce)
- * c1v_nadam_step:    Keras-2.2 Nadam; clip scale = clipnorm/norm if norm >= clipnorm, norm = sqrt(sum sq_partial)*grad_scale */
-typedef struct c1v_seg_desc { const float* slab; int64_t slab_stride; int32_t splits; int32_t reps; int64_t rep_stride; int64_t offset; int64_t count; int32_t frozen; int32_t pad; } c1v_seg_desc;
-int c1v_grad_finalize(const c1v_seg_desc* segs /*device*/, int32_t n_seg, int64_t max_count, float* grad, float* sq_partial, int32_t n_partial, void* stream);
+ * c1v_nadam_step:    Keras-2.2 Nadam; clip scale = clipnorm/norm if norm >= clipnorm, norm = sqrt(sched[7])*grad_scale */
+typedef struct c1v_seg_desc { const float* slab; int64_t slab_stride; int32_t splits; int32_t reps; int64_t rep_stride; int64_t offset; int64_t count; int32_t frozen; int32_t first_block; } c1v_seg_desc;
+/* segment i owns blocks [first_block_i, first_block_{i+1}) (ceil(count / C1V_CHUNK) each); sq_partial has total_blocks entries */
+int c1v_grad_finalize(const c1v_seg_desc* segs /*device*/, int32_t n_seg, int32_t total_blocks, float* grad, float* sq_partial, void* stream);
 int c1v_sqnorm_partial(const float* x, int64_t n, float* sq_partial, int32_t n_partial, void* stream);
 typedef struct c1v_nadam_args {
     float* p; const float* g; float* m; float* v; int64_t n;
-    const float* sq_partial; int32_t n_partial;
     float grad_scale;          /* 1/world_size after a sum all-reduce */
     float clipnorm;
-    const float* sched;        /* DEVICE [8]: lr, mu_t, mu_t1, 1-m_schedule_new, 1-m_schedule_next, 1-beta2^t, t, unused */
+    const float* sched;        /* DEVICE [8]: lr, mu_t, mu_t1, 1-m_schedule_new, 1-m_schedule_next, 1-beta2^t, t, sum of squares of the gradient */
     float beta1, beta2, eps;
     float* norm_out;           /* optional [1] */
 } c1v_nadam_args;
 int c1v_nadam_step(const c1v_nadam_args*, void* stream);
-/* state (DEVICE double[3]) = {iterations, m_schedule, lr}; writes the scalars of the NEXT step into sched[8] and
- * advances the state, so that a captured HIP graph can be replayed without host-side scalar updates. */
-int c1v_nadam_advance(double* state, float* sched, void* stream);
-/* number of sq_partial entries c1v_grad_finalize writes for (n_seg, max_count) */
-int c1v_grad_finalize_partials(int32_t n_seg, int64_t max_count);
+/* state (DEVICE double[3]) = {iterations, m_schedule, lr}; writes the scalars of the NEXT step into sched[8] (sched[7] =
+ * sum of sq_partial[0..n_partial)) and advances the state and, if given, the RNG step counter, so that a captured HIP
+ * graph can be replayed without host-side scalar updates. */
+int c1v_nadam_advance(double* state, float* sched, const float* sq_partial, int32_t n_partial, uint64_t* ctr, void* stream);
 
 /* ---- a10-i: EOS truncation + renormalisation (:542-565) ------------------------------------------------------
  * y [B][T][V] f32 -> out [B][T][V-1] f32, end_idx[B] */
@@ -281,6 +288,10 @@ int c1v_philox_normal(float* out, int64_t n, uint64_t seed, uint64_t stream_id, 
 int c1v_philox_bernoulli(uint8_t* out, int64_t n, float keep_prob, uint64_t seed, uint64_t stream_id, uint64_t offset,
                          const uint64_t* ctr, uint64_t ctr_mul, void* stream);
 int c1v_counter_add(uint64_t* ctr, uint64_t inc, void* stream);
+/* several requests in ONE launch: kind 0 = normal (float out), 1 = bernoulli (uint8 out, thr = keep_prob * 2^24);
+ * request i owns blocks [first_block_i, first_block_{i+1}) with ceil((n + 3) / 1024) + 1 blocks each */
+typedef struct c1v_rng_desc { void* out; int64_t n; int32_t kind; uint32_t thr; uint64_t stream_id; uint64_t offset; uint64_t ctr_mul; int32_t first_block; int32_t pad; } c1v_rng_desc;
+int c1v_philox_multi(const c1v_rng_desc* descs /*device*/, int32_t n_desc, int32_t total_blocks, uint64_t seed, const uint64_t* ctr, void* stream);
 
 /* ---- misc ---------------------------------------------------------------------------------------------------- */
 const char* c1v_last_error(void);
