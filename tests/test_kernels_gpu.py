@@ -1,0 +1,163 @@
+"""GPU tests of the individual C-ABI ops that the engine test does not pin on its own: nearest-word arg-max (a10-ii),
+EOS truncation (a10-i, against the reference's known-answer construction), Philox streams, and full-size
+(BASELINE.json configs[1], configs[2]) runs checked through the oracle or through size-independent properties."""
+import ctypes as C
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import vae_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _mods():
+    from conv1d_text_vae_amd import _lib, engine, geometry, synthetic
+    return _lib, engine, geometry, synthetic
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+# ------------------------------------------------------------------------------------------------ a10-ii
+@pytest.mark.parametrize('dtype,K,N,M', [('bf16', 300, 5000, 700), ('bf16', 302, 333, 129), ('bf16', 30, 1000, 64),
+                                         ('bf16', 60, 130, 10), ('f32', 300, 3000, 200), ('bf16', 100, 900, 77)])
+def test_vocab_argmax_matches_oracle(dtype, K, N, M):
+    L, engine, _, _ = _mods()
+    rng = np.random.RandomState(K + N)
+    W = rng.randn(N, K).astype(np.float32)
+    W /= np.linalg.norm(W, axis=1, keepdims=True)
+    q = W[rng.randint(0, N, size=M)] + 0.05 * rng.randn(M, K).astype(np.float32)
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    if dtype == 'bf16':       # compare on the values the kernel sees
+        W = torch.from_numpy(W).to(torch.bfloat16).float().numpy()
+        q = torch.from_numpy(q).to(torch.bfloat16).float().numpy()
+    dec = engine.VocabDecoder(W, M, dtype=dtype)
+    dec.load_queries(torch.from_numpy(q))
+    score, idx = dec.run()
+    torch.cuda.synchronize()
+    s64 = q.astype(np.float64) @ W.astype(np.float64).T
+    ref_idx = s64.argmax(axis=1)
+    got = idx.cpu().numpy()
+    # decoded ids are bit-exact except on documented near-ties: accept a different index only if its exact score is
+    # within fp32 accumulation noise of the maximum
+    bad = got != ref_idx
+    if bad.any():
+        gap = s64[np.arange(M), ref_idx][bad] - s64[np.arange(M), got][bad]
+        assert np.all(gap < 2e-6), gap.max()
+    np.testing.assert_allclose(score.cpu().numpy(), s64.max(axis=1), rtol=0, atol=2e-5)
+
+
+def test_vocab_argmax_ties_pick_lowest_index_and_n_base():
+    L, engine, _, _ = _mods()
+    K, N = 64, 300
+    W = np.zeros((N, K), dtype=np.float32)
+    W[np.arange(N), np.arange(N) % K] = 1.0          # rows r and r+64k are identical
+    q = np.eye(K, dtype=np.float32)[[5, 63, 0]]
+    dec = engine.VocabDecoder(W, 3, dtype='bf16', n_base=1000)
+    dec.load_queries(torch.from_numpy(q))
+    score, idx = dec.run()
+    assert idx.cpu().tolist() == [1005, 1063, 1000] and score.cpu().tolist() == [1.0, 1.0, 1.0]
+
+
+def test_vocab_argmax_c3_shape_self_retrieval():
+    """BASELINE configs[2] shape (M = 8192*64 rows, 200 000-row vocabulary, emb 300): every query is a vocabulary row,
+    so the fused GEMM + arg-max must return exactly that row (size-independent property; the oracle would need 63 TFLOP)."""
+    L, engine, _, synthetic = _mods()
+    N, K, M = 200000, 302, 8192 * 64
+    W = synthetic.synthetic_vocab(N - 2, K - 2, seed=3)
+    Wb = torch.from_numpy(W).to(torch.bfloat16)
+    # drop duplicates that bf16 rounding could create: not expected for random 300-d rows
+    rng = np.random.RandomState(0)
+    pick = rng.randint(0, N, size=M)
+    dec = engine.VocabDecoder(W, M, dtype='bf16')
+    dec.load_queries(Wb[torch.from_numpy(pick)].float())
+    score, idx = dec.run()
+    torch.cuda.synchronize()
+    assert np.array_equal(idx.cpu().numpy(), pick)
+    assert float(score.min()) > 0.99
+
+
+# ------------------------------------------------------------------------------------------------ a10-i
+def test_eos_truncate_known_answers():
+    """The construction of reference tests/test_conv1d_text_vae.py:1544-1605, batched, through the HIP kernel."""
+    L, _, _, _ = _mods()
+    lib = L.load()
+    rng = np.random.RandomState(1)
+    B, T, V = 7, 20, 7
+    src = np.concatenate([rng.uniform(-1, 1, (B, T, V - 1)), rng.uniform(-3, -2, (B, T, 1))], axis=2).astype(np.float32)
+    ends = [11, 1, 0, 19, 5, T, 3]          # T = no EOS step at all
+    true = np.zeros((B, T, V - 1), dtype=np.float32)
+    for b, e in enumerate(ends):
+        if e < T:
+            src[b, e] = 0.0
+            src[b, e, V - 1] = 1.0
+        if b == 1:
+            src[b, 0, V - 1] = 1.5          # EOS wins at step 0 -> end = max(0, 1) = 1   (:1582-1585)
+        stop = max(e, 1) if e < T else T
+        if b == 1:
+            stop = 1
+        true[b, :stop] = src[b, :stop, :V - 1] / np.linalg.norm(src[b, :stop, :V - 1], axis=-1, keepdims=True)
+    y = torch.from_numpy(src).cuda()
+    out = torch.zeros(B, T, V - 1, device='cuda')
+    end = torch.zeros(B, dtype=torch.int32, device='cuda')
+    L.check(lib.c1v_eos_truncate_normalize(y.data_ptr(), B, T, V, out.data_ptr(), end.data_ptr(), _stream()))
+    np.testing.assert_allclose(out.cpu().numpy(), true, atol=1e-6)
+    np.testing.assert_allclose(out.cpu().numpy(), O.postprocess_reconstructed_word_vectors(src), atol=1e-6)
+    assert np.array_equal(end.cpu().numpy(), O.eos_end_index(src))
+
+
+# ------------------------------------------------------------------------------------------------ RNG
+def test_philox_streams_match_oracle():
+    L, _, _, _ = _mods()
+    lib = L.load()
+    n = 10007
+    out = torch.zeros(n, device='cuda')
+    L.check(lib.c1v_philox_normal(out.data_ptr(), n, 99, 5, 13, None, 0, _stream()))
+    np.testing.assert_allclose(out.cpu().numpy(), O.philox_normal(n, seed=99, stream=5, offset=13), rtol=2e-4, atol=2e-5)
+    m = torch.zeros(n, dtype=torch.uint8, device='cuda')
+    L.check(lib.c1v_philox_bernoulli(m.data_ptr(), n, 0.7, 99, 6, 2, None, 0, _stream()))
+    assert np.array_equal(m.cpu().numpy(), O.philox_bernoulli(n, 0.7, seed=99, stream=6, offset=2))
+
+
+# ------------------------------------------------------------------------------------------------ full size (C2)
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_c2_full_size_step_matches_oracle(dtype):
+    """BASELINE configs[1]: batch 256, seq_len 32, emb 300, latent 256, vocabulary 8192 -- one train step against the
+    oracle (float32 oracle, a few seconds), then 3 more graph-replayed steps must keep the loss finite and decreasing."""
+    L, engine, geometry, synthetic = _mods()
+    B, T, E, D, N = 256, 32, 300, 256, 8192
+    V = E + 2
+    W = synthetic.synthetic_vocab(N - 2, E)
+    x, ids = synthetic.synthetic_batch(W, N, B, T, T)
+    og = O.VAEGeometry(T, T, V, V, (128,), 3, D)
+    params = O.init_params(og, seed=0)
+    rng = np.random.RandomState(0)
+    eps = rng.standard_normal((B, D)).astype(np.float32)
+    me = rng.uniform(size=(B, og.flat_size)) < 0.7
+    md = rng.uniform(size=(B, D)) < 0.7
+    loss, grads, acts = O.train_forward_backward(og, params, W, x, ids, eps, me, md)
+    g = geometry.Geometry(T, T, V, V, (128,), 3, D)
+    eng = engine.VAEEngine(g, B, W, dtype=dtype, weights=params)
+    eng.load_batch(x, ids)
+    eng.eps.copy_(torch.from_numpy(eps))
+    eng.keep_e.copy_(torch.from_numpy(me.astype(np.uint8)))
+    eng.keep_d.copy_(torch.from_numpy(md.astype(np.uint8)))
+    eng._run(eng.train_ops(False))
+    torch.cuda.synchronize()
+    tol = 2e-4 if dtype == 'f32' else 2e-2
+    y = eng.y_pred().cpu().numpy()
+    assert np.abs(y - acts['y_pred']).max() / np.abs(acts['y_pred']).max() < tol
+    assert abs(eng.loss() - loss) < (2e-4 if dtype == 'f32' else 1e-2) * abs(loss)
+    gg = eng.get_grads()
+    for k_, ref in grads.items():
+        err = np.linalg.norm(gg[k_].astype(np.float64) - ref) / max(np.linalg.norm(ref), 1e-30)
+        assert err < (1e-3 if dtype == 'f32' else 5e-2), (k_, err)
+    losses = []
+    for _ in range(4):
+        eng.train_step(use_graph=True, fixed_rng=True)
+        losses.append(eng.loss())
+    assert np.all(np.isfinite(losses)) and losses[-1] < losses[0]
