@@ -93,7 +93,7 @@ class XentFinishArgs(C.Structure):
                 ('ones_col', C.c_int32), ('yhat', C.c_void_p), ('w', C.c_void_p), ('dtype', C.c_int32),
                 ('rnorm', C.c_void_p), ('qscale', C.c_float), ('ids', C.c_void_p), ('B', C.c_int32), ('T', C.c_int32),
                 ('V', C.c_int32), ('B_global', C.c_int32), ('xent_rows', C.c_void_p), ('xent_b', C.c_void_p),
-                ('dy', Seq)]
+                ('dy', Seq), ('y', C.c_void_p), ('ldy', C.c_int64)]
 
 
 class SegDesc(C.Structure):

@@ -58,7 +58,7 @@ class Buf:
 
     def valid(self) -> torch.Tensor:
         """[batch, len, c] view of the valid region (testing / export)."""
-        rows = self.t[: self.batch * self.pitch].view(self.batch, self.pitch, self.cp)
+        rows = self.t[: self.batch * self.pitch * self.cp].view(self.batch, self.pitch, self.cp)
         return rows[:, self.off:self.off + self.len, :self.c]
 
 
@@ -428,7 +428,7 @@ class VAEEngine:
                 self.ut.data_ptr(), self.x_splits, self.kp, self.m_pad, self.ones_col, self.yhat.data_ptr(),
                 self.w_vocab.data_ptr(), self.code, self.rnorm.data_ptr(), self.qscale, self.ids_in.data_ptr(), B,
                 g.output_text_size, self.V, self.Bg, self.xent_rows.data_ptr(), self.xent_b.data_ptr(),
-                self.dOf.seq() if train else _null_seq())))
+                self.dOf.seq() if train else _null_seq(), self.Y.t.data_ptr(), self.V)))
             f_red = self.lib.c1v_loss_reduce
 
             def red():

@@ -226,6 +226,7 @@ typedef struct c1v_xent_finish_args {
     float* xent_rows;         /* [B*T] masked per-row cross entropy */
     float* xent_b;            /* [B] per-sample sum_t xent*mask / sum_t mask */
     c1v_seq dy;               /* or dy.data == NULL for loss only */
+    const float* y; int64_t ldy;   /* optional fp32 decoder output [M][ldy]: yhat = y*rnorm in fp32 for the normalisation backward */
 } c1v_xent_finish_args;
 int c1v_cos_softmax_finish(const c1v_xent_finish_args*, void* stream);
 int c1v_cos_softmax_xent_fwd(const c1v_xent_accum_args*, void* stream);   /* need_u = 0 alias */
