@@ -122,6 +122,12 @@ class VocabArgmaxArgs(C.Structure):
                 ('idx', C.c_void_p), ('logits', C.c_void_p), ('n_chunk', C.c_int32)]
 
 
+class VocabTopnArgs(C.Structure):
+    _fields_ = [('q', C.c_void_p), ('dtype', C.c_int32), ('M', C.c_int32), ('kp', C.c_int32), ('w', C.c_void_p),
+                ('N', C.c_int32), ('n_base', C.c_int32), ('logits', C.c_void_p), ('ld', C.c_int64),
+                ('topn', C.c_int32), ('score', C.c_void_p), ('idx', C.c_void_p)]
+
+
 # every symbol include/c1dvae.h declares: name -> (argtypes, restype)
 _P = C.POINTER
 SYMBOLS = {
@@ -154,7 +160,10 @@ SYMBOLS = {
     'c1v_nadam_advance': ([C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p], C.c_int),
     'c1v_eos_truncate_normalize': ([C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p],
                                    C.c_int),
+    'c1v_eos_truncate_normalize_f64': ([C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                                        C.c_void_p], C.c_int),
     'c1v_vocab_argmax': ([_P(VocabArgmaxArgs), C.c_void_p], C.c_int),
+    'c1v_vocab_topn': ([_P(VocabTopnArgs), C.c_void_p], C.c_int),
     'c1v_argmax_merge': ([C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p], C.c_int),
     'c1v_philox_normal': ([C.c_void_p, C.c_int64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint64,
                            C.c_void_p], C.c_int),

@@ -377,6 +377,32 @@ __global__ __launch_bounds__(256) void row_argmax_kernel(const float* __restrict
     }
 }
 
+// top-n of every row of materialised logits [M][ld] (a10-ii with topn > 1: gensim `similar_by_vector(v, topn)`).
+// Round r selects the best entry strictly after round r-1's winner in the total order (score descending, index
+// ascending), so no per-lane candidate lists are needed; n rounds re-read the row from L2/HBM (topn is small).
+__global__ __launch_bounds__(256) void row_topn_kernel(const float* __restrict__ logits, int M, int64_t ld, int N, int n_base, int topn,
+                                                       float* __restrict__ score, int* __restrict__ idx) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float* lr = logits + (int64_t)row * ld;
+    float prev_v = 3.4e38f; int prev_i = -1;
+    for (int r = 0; r < topn; ++r) {
+        float best = -3.4e38f; int bi = 0x7fffffff;
+        for (int n = lane; n < N; n += 64) {
+            const float v = lr[n];
+            const bool after = (v < prev_v) || (v == prev_v && n > prev_i);
+            if (after && v > best) { best = v; bi = n; }
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64);
+            if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+        }
+        if (lane == 0) { score[(int64_t)row * topn + r] = best; idx[(int64_t)row * topn + r] = bi == 0x7fffffff ? -1 : bi + n_base; }
+        prev_v = best; prev_i = bi;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------
 // host entry points
 // ------------------------------------------------------------------------------------------------------
@@ -562,5 +588,26 @@ extern "C" int c1v_vocab_argmax(const c1v_vocab_argmax_args* a, void* stream) {
                            nc0 + a->n_base, a->score, a->idx, ch == 0 ? 1 : 0);
         C1V_LAUNCH_CHECK();
     }
+    return 0;
+}
+
+extern "C" int c1v_vocab_topn(const c1v_vocab_topn_args* a, void* stream) {
+    C1V_REQUIRE(a && a->q && a->w && a->score && a->idx && a->logits, "vocab_topn: null argument");
+    C1V_REQUIRE(a->dtype == C1V_F32 || a->dtype == C1V_BF16, "vocab_topn: bad dtype");
+    C1V_REQUIRE(a->M > 0 && a->N > 0 && a->kp % 32 == 0 && a->ld >= a->N, "vocab_topn: bad shape M=%d N=%d kp=%d ld=%lld", a->M, a->N, a->kp, (long long)a->ld);
+    C1V_REQUIRE(a->topn > 0 && a->topn <= a->N && a->topn <= 1024, "vocab_topn: topn (%d) must be in [1, min(N, 1024)]", a->topn);
+    hipStream_t st = (hipStream_t)stream;
+    const int es = c1v_esize(a->dtype);
+    NtParams p{};
+    p.A = (const char*)a->q; p.a_bstride_b = (int64_t)a->kp * es; p.lda_b = (int64_t)a->kp * es; p.a_off = 0;
+    p.W = (const char*)a->w; p.ldw_b = (int64_t)a->kp * es; p.Kb = (int64_t)a->kp * es;
+    p.e = EpiDev{};
+    p.e.row_mode = C1V_ROW_STORE; p.e.dst = a->logits; p.e.dst_dtype = C1V_F32; p.e.dst_bstride = a->ld; p.e.dst_off = 0; p.e.dst_len = 1;
+    p.e.dst_cp = (int)a->ld; p.e.dst_c = a->N; p.e.act_rowmul = 1; p.e.M = a->M; p.e.Le = 1; p.e.nrows = 1; p.e.N = a->N;
+    C1V_REQUIRE(a->ld < (1ll << 31), "vocab_topn: ld too large");
+    int rc = c1v_launch_nt(a->dtype, p, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(row_topn_kernel, dim3((unsigned)c1v_cdiv(a->M, 4)), dim3(256), 0, st, a->logits, a->M, a->ld, a->N, a->n_base, a->topn, a->score, a->idx);
+    C1V_LAUNCH_CHECK();
     return 0;
 }

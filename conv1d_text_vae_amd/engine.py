@@ -399,6 +399,9 @@ class VAEEngine:
                                                        self.wop['out_fwd'].data_ptr(), self.wld['out_fwd'], self.V, e)))
             return ops
 
+        self.ops_gather_in = None          # built by set_input_table (device-side batch assembly)
+        if getattr(self, 'in_table', None) is not None:
+            self._build_gather()
         self.ops_enc_train = enc_fwd(True)
         self.ops_enc_infer = enc_fwd(False)
         self.ops_lat_train = [op('c1v_latent_head_fwd', self._lat_train)]
@@ -631,6 +634,30 @@ class VAEEngine:
             t.copy_(s)
         self._pack_all()
 
+    def set_input_table(self, table: np.ndarray):
+        """Device-side batch assembly (SequenceForVAE.__getitem__ :1374-1390 without the Python loops): `table` is the
+        input word-vector matrix [N_in, V_in]; a batch is then given as int32 row ids [B, T_in] (-1 = all-zero row) in
+        `in_ids` and c1v_gather_input builds the encoder operand directly."""
+        t = np.ascontiguousarray(table, dtype=np.float32)
+        if t.ndim != 2 or t.shape[1] != self.g.input_vector_size:
+            raise ValueError('input table must be [N, {0}]'.format(self.g.input_vector_size))
+        self.in_table = torch.from_numpy(t).to(self.dev)
+        self.in_ids = torch.full((self.B, self.g.input_text_size), -1, dtype=torch.int32, device=self.dev)
+        self._build_gather()
+        self._graphs = {k: v for k, v in self._graphs.items() if not k.endswith('@ids')}
+
+    def _build_gather(self):
+        self.ops_gather_in = [self._op('c1v_gather_input', L.GatherInputArgs(
+            self.in_table.data_ptr(), self.in_table.shape[1], self.in_ids.data_ptr(), self.g.input_text_size,
+            self.g.input_vector_size, self.Xe[0].seq()))]
+
+    def _in_ops(self, from_ids: bool):
+        if not from_ids:
+            return self.ops_pack_in
+        if self.ops_gather_in is None:
+            raise L.C1VError('from_ids=True needs set_input_table() first')
+        return self.ops_gather_in
+
     def load_batch(self, x: Optional[np.ndarray] = None, ids: Optional[np.ndarray] = None):
         if x is not None:
             self.x_in.copy_(torch.as_tensor(x, dtype=torch.float32), non_blocking=True)
@@ -651,26 +678,27 @@ class VAEEngine:
             self._run(main_ops)
         main.wait_stream(side)
 
-    def train_ops(self, with_rng: bool):
-        fwd = (self.ops_rng if with_rng else []) + self.ops_pack_in + self.ops_enc_train + self.ops_lat_train + \
+    def train_ops(self, with_rng: bool, from_ids: bool = False):
+        fwd = (self.ops_rng if with_rng else []) + self._in_ops(from_ids) + self.ops_enc_train + self.ops_lat_train + \
             self.ops_dec + self.ops_loss_train
         return fwd + [self._run_backward] + self.ops_finalize
 
-    def train_step(self, use_graph: bool = True, fixed_rng: bool = False, all_reduce=None):
+    def train_step(self, use_graph: bool = True, fixed_rng: bool = False, all_reduce=None, from_ids: bool = False):
         """One fit step on the batch resident in x_in / ids_in: forward, loss, backward, clip, Nadam, operand refresh.
         fixed_rng: eps / keep_e / keep_d were filled by the caller (parity runs)."""
         if self.N == 0:
             raise L.C1VError('train_step needs the vocabulary matrix (set_vocab)')
+        sfx = '@ids' if from_ids else ''
         if self.world == 1:
-            ops = self.train_ops(not fixed_rng) + self.ops_update
+            ops = self.train_ops(not fixed_rng, from_ids) + self.ops_update
             if use_graph:
-                self._graph('train_fixed' if fixed_rng else 'train', ops)
+                self._graph(('train_fixed' if fixed_rng else 'train') + sfx, ops)
             else:
                 self._run(ops)
         else:
-            a, b = self.train_ops(not fixed_rng), self.ops_update
+            a, b = self.train_ops(not fixed_rng, from_ids), self.ops_update
             if use_graph:
-                self._graph('train_a_fixed' if fixed_rng else 'train_a', a)
+                self._graph(('train_a_fixed' if fixed_rng else 'train_a') + sfx, a)
             else:
                 self._run(a)
             all_reduce(self.grads)                      # RCCL sum over ranks; loss terms carry 1/B_global already
@@ -679,14 +707,25 @@ class VAEEngine:
             else:
                 self._run(b)
 
-    def eval_step(self, use_graph: bool = True, fixed_rng: bool = False):
+    def eval_step(self, use_graph: bool = True, fixed_rng: bool = False, from_ids: bool = False):
         """Validation loss of the resident batch (dropout off, eps still sampled -- Keras test phase of FullVAE)."""
-        ops = ([] if fixed_rng else self.ops_rng_eval) + self.ops_pack_in + self.ops_enc_infer + self.ops_lat_eval + \
+        ops = ([] if fixed_rng else self.ops_rng_eval) + self._in_ops(from_ids) + self.ops_enc_infer + self.ops_lat_eval + \
             self.ops_dec + self.ops_loss_eval
         if use_graph:
-            self._graph('eval_fixed' if fixed_rng else 'eval', ops)
+            self._graph(('eval_fixed' if fixed_rng else 'eval') + ('@ids' if from_ids else ''), ops)
         else:
             self._run(ops)
+
+    def sample_reconstruct(self, use_graph: bool = True, from_ids: bool = False, postprocess: bool = True) -> torch.Tensor:
+        """FullVAE.predict_on_batch (:1462-1464): dropout off, z SAMPLED (the stage-2 generator trains on these), then
+        optionally postprocess_reconstructed_word_vectors."""
+        ops = self.ops_rng_eval + self._in_ops(from_ids) + self.ops_enc_infer + self.ops_lat_eval + self.ops_dec + \
+            (self.ops_post if postprocess else [])
+        if use_graph:
+            self._graph('sample_recon' + ('_post' if postprocess else '') + ('@ids' if from_ids else ''), ops)
+        else:
+            self._run(ops)
+        return self.post if postprocess else self.y_pred()
 
     def loss(self) -> float:
         return float(self.loss_out[0].item())
@@ -772,3 +811,69 @@ class VocabDecoder:
                               self.logits.data_ptr() if self.logits is not None else None, self.n_chunk)
         L.call('c1v_vocab_argmax', C.byref(a), C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream))
         return self.score[:self.M], self.idx[:self.M]
+
+
+class VocabTopN:
+    """a10-ii with topn > 1: gensim `similar_by_vector(v, topn)` (reference :587) over a table of unit rows.
+    fp32 MFMA GEMM into a logits scratch + fused row top-n (c1v_vocab_topn); queries are processed in row chunks so
+    that the scratch stays below `scratch_bytes`."""
+
+    def __init__(self, vocab_norm: np.ndarray, device: str = 'cuda:0', dtype: str = 'f32', scratch_bytes: int = 1 << 28):
+        if not torch.cuda.is_available():
+            raise L.C1VError('VocabTopN needs a GPU: nearest-word search runs on the HIP kernels only.')
+        self.lib = L.load()
+        self.device_str = device
+        self.dev = torch.device(device)
+        self.tdt = torch.bfloat16 if dtype == 'bf16' else torch.float32
+        self.code = L.BF16 if dtype == 'bf16' else L.F32
+        W = np.asarray(vocab_norm, dtype=np.float32)
+        self.N, self.K = W.shape
+        self.kp = _pad(self.K, 64)
+        host = np.zeros((self.N + L.SLACK_ROWS, self.kp), dtype=np.float32)
+        host[:self.N, :self.K] = W
+        self.w = torch.from_numpy(host).to(self.dev).to(self.tdt).contiguous()
+        self.ld = _pad(self.N, 64)
+        self.m_chunk = int(max(1, min(4096, scratch_bytes // (4 * self.ld))))
+        self.logits = torch.zeros(self.m_chunk * self.ld, dtype=torch.float32, device=self.dev)
+        self.q = torch.zeros((self.m_chunk + L.SLACK_ROWS) * self.kp, dtype=self.tdt, device=self.dev)
+
+    def run(self, queries: np.ndarray, topn: int, n_base: int = 0):
+        """queries [M, K] (used as given: normalise beforehand).  Returns (score [M, topn] f32, index [M, topn] i32) as
+        NumPy arrays, best first, ties -> lowest index."""
+        q = torch.as_tensor(np.asarray(queries, dtype=np.float32))
+        M = q.shape[0]
+        if q.shape[1] != self.K:
+            raise ValueError('queries must be [M, {0}]'.format(self.K))
+        if not (0 < topn <= self.N):
+            raise ValueError('topn must be in [1, {0}]'.format(self.N))
+        score = torch.empty((M, topn), dtype=torch.float32, device=self.dev)
+        idx = torch.empty((M, topn), dtype=torch.int32, device=self.dev)
+        st = C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
+        qv = self.q[: self.m_chunk * self.kp].view(self.m_chunk, self.kp)
+        for m0 in range(0, M, self.m_chunk):
+            m = min(self.m_chunk, M - m0)
+            qv[:m, :self.K].copy_(q[m0:m0 + m].to(self.dev))
+            a = L.VocabTopnArgs(self.q.data_ptr(), self.code, m, self.kp, self.w.data_ptr(), self.N, n_base,
+                                self.logits.data_ptr(), self.ld, topn, score[m0:].data_ptr(), idx[m0:].data_ptr())
+            L.call('c1v_vocab_topn', C.byref(a), st)
+        return score.cpu().numpy(), idx.cpu().numpy()
+
+
+def postprocess_word_vectors(word_vectors: np.ndarray, device: str = 'cuda:0'):
+    """a10-i on NumPy data (the static helper `postprocess_reconstructed_word_vectors`, reference :542-565): upload,
+    c1v_eos_truncate_normalize (float32) or its float64 variant (any other dtype is computed in float64 and cast back,
+    so the dtype of the argument is kept, as the reference does), download.  Returns (out [B,T,V-1], end_idx [B])."""
+    if not torch.cuda.is_available():
+        raise L.C1VError('postprocess_reconstructed_word_vectors needs a GPU: the HIP kernel is the only implementation.')
+    lib = L.load()
+    a = np.asarray(word_vectors)
+    B, T, V = a.shape
+    dev = torch.device(device)
+    f32 = a.dtype == np.float32
+    src = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32 if f32 else np.float64)).to(dev)
+    out = torch.empty((B, T, V - 1), dtype=src.dtype, device=dev)
+    end = torch.empty((B,), dtype=torch.int32, device=dev)
+    fn = lib.c1v_eos_truncate_normalize if f32 else lib.c1v_eos_truncate_normalize_f64
+    L.check(fn(src.data_ptr(), B, T, V, out.data_ptr(), end.data_ptr(),
+               C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), 'c1v_eos_truncate_normalize')
+    return out.cpu().numpy().astype(a.dtype, copy=False), end.cpu().numpy()

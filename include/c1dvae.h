@@ -264,6 +264,9 @@ int c1v_nadam_advance(double* state, float* sched, const float* sq_partial, int3
 /* ---- a10-i: EOS truncation + renormalisation (:542-565) ------------------------------------------------------
  * y [B][T][V] f32 -> out [B][T][V-1] f32, end_idx[B] */
 int c1v_eos_truncate_normalize(const float* y, int32_t B, int32_t T, int32_t V, float* out, int32_t* end_idx, void* stream);
+/* float64 variant: the reference's static helper keeps the dtype of its NumPy argument (:547-550) and its known-answer
+ * tests compare float64 values to 7 places (tests/test_conv1d_text_vae.py:1544-1605) */
+int c1v_eos_truncate_normalize_f64(const double* y, int32_t B, int32_t T, int32_t V, double* out, int32_t* end_idx, void* stream);
 
 /* ---- a10-ii: nearest vocabulary row (gensim similar_by_vector arithmetic, :587) -------------------------------
  * score[m] = max_n q_m . w_n, idx[m] = lowest n attaining it (n_base added), over the caller's shard of rows.
@@ -277,6 +280,18 @@ typedef struct c1v_vocab_argmax_args {
     float* logits; int32_t n_chunk;
 } c1v_vocab_argmax_args;
 int c1v_vocab_argmax(const c1v_vocab_argmax_args*, void* stream);
+/* topn > 1 (`similar_by_vector(v, topn)` inside find_best_words, :587): NT GEMM into the caller's `logits` scratch
+ * ([M][ld] f32, ld >= N) + per-row selection; score/idx are [M][topn], best first, ties -> lowest index.  q [M][kp] and
+ * w [>= N rows][kp] follow the operand rules of c1v_dense_fwd (rows zero-padded to whole 128-byte K tiles, 64 readable
+ * rows past the end). */
+typedef struct c1v_vocab_topn_args {
+    const void* q; int32_t dtype; int32_t M, kp;
+    const void* w; int32_t N; int32_t n_base;
+    float* logits; int64_t ld;
+    int32_t topn;
+    float* score; int32_t* idx;
+} c1v_vocab_topn_args;
+int c1v_vocab_topn(const c1v_vocab_topn_args*, void* stream);
 /* merge per-shard results gathered from R ranks: ties -> lowest global index */
 int c1v_argmax_merge(const float* scores /*[R][M]*/, const int32_t* idxs, int32_t R, int32_t M, float* score, int32_t* idx, void* stream);
 
