@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libc1dvae.so')
+LIB_PATH = os.environ.get('C1V_LIB') or os.path.join(_HERE, 'libc1dvae.so')      # C1V_LIB: diagnostic builds only
 
 F32 = 0
 BF16 = 1

@@ -44,6 +44,18 @@ __device__ __forceinline__ void store_any(void* p, int dtype, int64_t i, float v
     if (dtype == C1V_F32) ((float*)p)[i] = v; else ((bf16_raw*)p)[i] = f32_to_bf16(v);
 }
 
+// LDS-DMA (global -> LDS, 16 bytes per lane, lane-linear: lane L lands at lds_addr + 16 L) issued through inline asm ON
+// PURPOSE: for the builtin, the compiler cannot tell which LDS bytes a request in flight will write, so it puts
+// `s_waitcnt vmcnt(0)` in front of the next ds_read -- the request just issued for a LATER stage is waited for at once
+// and a multi-stage ring degenerates into one exposed memory latency per K step (measured: 0.9 us per step).  Through
+// asm the request is invisible to that bookkeeping; the kernels count their own `s_waitcnt vmcnt(N)` + barrier before a
+// stage is read.  `lds_addr` is wave-uniform (LDS byte address of the wave's 1 KiB piece).
+__device__ __forceinline__ uint32_t c1v_lds_addr(const void* p) { return (uint32_t)(uintptr_t)C1V_LDS_PTR(const void, p); }
+__device__ __forceinline__ void c1v_glds16(const void* gsrc, uint32_t lds_addr) {
+    const uint32_t a = __builtin_amdgcn_readfirstlane(lds_addr);      // an "s" operand must really live in an SGPR
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(a), "v"(gsrc) : "memory", "m0");
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -20,66 +20,6 @@
 #include "c1v_common.h"
 
 // ------------------------------------------------------------------------------------------------------
-// fused epilogue
-// ------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float epi_act_mask(const EpiDev& e, int b, int row, int c) {
-    if (!e.act) return 1.0f;
-    const int64_t idx = (int64_t)b * e.act_bstride + (int64_t)(e.act_off + row * e.act_rowmul) * e.act_cp + c;
-    return load_any(e.act, e.act_dtype, idx) > 0.0f ? e.act_scale : 0.0f;
-}
-__device__ __forceinline__ void epi_store(const EpiDev& e, int b, int row, int c, float v) {
-    const int64_t idx = (int64_t)b * e.dst_bstride + (int64_t)(e.dst_off + row) * e.dst_cp + c;
-    store_any(e.dst, e.dst_dtype, idx, v);
-}
-
-// single-row modes: STORE, UP2, UNPOOL.  (b, u) = sample / row of the GEMM row, already range-checked.
-__device__ __forceinline__ void epi_row(const EpiDev& e, int b, int u, int n, float v) {
-    if (n >= e.N) return;
-    if (e.bias) v += e.bias[n];
-    if (e.relu) v = fmaxf(v, 0.0f);
-    if (e.exp2) v = exp2f(v);
-    int t = u, c = n;
-    if (e.reshape_w > 0) { t = n / e.reshape_w; c = n - t * e.reshape_w; }
-    if (e.row_mode == C1V_ROW_STORE) {
-        if (t >= e.dst_len) return;
-        v *= epi_act_mask(e, b, t, c);
-        if (e.keep) v = e.keep[(int64_t)b * e.sel_bstride + (int64_t)t * e.sel_cp + c] ? v * e.keep_scale : 0.0f;
-        epi_store(e, b, t, c, v);
-    } else if (e.row_mode == C1V_ROW_UP2) {
-        if (2 * t < e.dst_len) epi_store(e, b, 2 * t, c, v);
-        if (2 * t + 1 < e.dst_len) epi_store(e, b, 2 * t + 1, c, v);
-    } else {   // UNPOOL: t indexes the pooled row
-        if (2 * t + 1 >= e.dst_len) return;
-        v *= epi_act_mask(e, b, t, c);
-        const int s = e.sel[(int64_t)b * e.sel_bstride + (int64_t)t * e.sel_cp + c] ? 1 : 0;
-        epi_store(e, b, 2 * t + s, c, v);
-        epi_store(e, b, 2 * t + 1 - s, c, 0.0f);
-    }
-}
-
-// pair modes: POOL2, PAIRSUM.  u is even and Le is even, so (u, u+1) are rows of one sample.
-__device__ __forceinline__ void epi_pair(const EpiDev& e, int b, int u, int n, float v0, float v1) {
-    if (n >= e.N) return;
-    const int t = u >> 1;
-    if (t >= e.dst_len) return;
-    if (e.bias) { const float bv = e.bias[n]; v0 += bv; v1 += bv; }
-    if (e.relu) { v0 = fmaxf(v0, 0.0f); v1 = fmaxf(v1, 0.0f); }
-    if (e.row_mode == C1V_ROW_POOL2) {
-        if (u + 1 >= e.nrows) return;
-        const int s = v1 > v0 ? 1 : 0;            // first maximum wins ties
-        float v = s ? v1 : v0;
-        const int64_t si = (int64_t)b * e.sel_bstride + (int64_t)t * e.sel_cp + n;
-        if (e.sel) e.sel[si] = (uint8_t)s;
-        if (e.keep) v = e.keep[si] ? v * e.keep_scale : 0.0f;
-        epi_store(e, b, t, n, v);
-    } else {   // PAIRSUM
-        float v = (u < e.nrows ? v0 : 0.0f) + (u + 1 < e.nrows ? v1 : 0.0f);
-        v *= epi_act_mask(e, b, t, n);
-        epi_store(e, b, t, n, v);
-    }
-}
-
-// ------------------------------------------------------------------------------------------------------
 // fragment MMA: 16 bytes of K per lane
 // ------------------------------------------------------------------------------------------------------
 template <typename T> __device__ __forceinline__ void mma16(f32x4_t& acc, const uint4& a, const uint4& b);
@@ -93,9 +33,7 @@ template <> __device__ __forceinline__ void mma16<float>(f32x4_t& acc, const uin
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
 }
 
-__device__ __forceinline__ void glds16(const char* src, char* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, C1V_LDS_PTR(void, lds_wave_base), 16, 0, 0);
-}
+__device__ __forceinline__ void glds16(const char* src, char* lds_wave_base) { c1v_glds16(src, c1v_lds_addr(lds_wave_base)); }
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 __device__ __forceinline__ void block_barrier() {
     __builtin_amdgcn_s_barrier();
@@ -109,8 +47,143 @@ __device__ __forceinline__ int lds_off(int row, int ch) { return row * 128 + ((c
 // ------------------------------------------------------------------------------------------------------
 // NT kernel
 // ------------------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------------------
+// fused epilogue (c1v_epilogue in include/c1dvae.h) over a tile parked in LDS
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void store4(const EpiDev& e, int64_t idx, const float v[4], int count) {
+    // `count` leading values are stored; one 8- / 16-byte store when all four are and the address allows it
+    if (count == 4) {
+        if (e.dst_dtype == C1V_F32) {
+            float* d = (float*)e.dst + idx;
+            if ((((uintptr_t)d) & 15) == 0) { *(float4*)d = make_float4(v[0], v[1], v[2], v[3]); return; }
+        } else {
+            bf16_raw* d = (bf16_raw*)e.dst + idx;
+            if ((((uintptr_t)d) & 7) == 0) { *(uint2*)d = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])); return; }
+        }
+    }
+    for (int k = 0; k < count; ++k) store_any(e.dst, e.dst_dtype, idx + k, v[k]);
+}
+
+template <int BM, int BN>
+__device__ __forceinline__ void epilogue_tile(const EpiDev& e, const float* ct, int LDC, int m0, int n0, int tid) {
+    constexpr int G = BN / 4;                                  // 4-channel groups per tile row
+    const bool pairs = (e.row_mode == C1V_ROW_POOL2) || (e.row_mode == C1V_ROW_PAIRSUM);
+    const int items = (pairs ? BM / 2 : BM) * G;
+#pragma unroll 1
+    for (int it = tid; it < items; it += 256) {
+        const int rr = it / G, g = it - rr * G;
+        const int row = pairs ? 2 * rr : rr;
+        const int m = m0 + row, n = n0 + 4 * g;
+        if (m >= e.M || n >= e.N) continue;
+        const int b = m / e.Le, u = m - b * e.Le;
+        const int cnt = e.N - n < 4 ? e.N - n : 4;             // valid channels of this group
+        const float4 c0 = *(const float4*)(ct + row * LDC + 4 * g);
+        float v[4] = {c0.x, c0.y, c0.z, c0.w};
+        float w[4] = {0.f, 0.f, 0.f, 0.f};
+        if (pairs) { const float4 c1 = *(const float4*)(ct + (row + 1) * LDC + 4 * g); w[0] = c1.x; w[1] = c1.y; w[2] = c1.z; w[3] = c1.w; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float bv = (e.bias && k < cnt) ? e.bias[n + k] : 0.0f;
+            v[k] += bv; w[k] += bv;
+            if (e.relu) { v[k] = fmaxf(v[k], 0.0f); w[k] = fmaxf(w[k], 0.0f); }
+            if (e.exp2) v[k] = exp2f(v[k]);
+        }
+        if (e.reshape_w > 0) {
+            // column split (t, c) = divmod(n, reshape_w): element-wise (only the two small dense layers use it)
+            if (u >= e.nrows) continue;
+            for (int k = 0; k < cnt; ++k) {
+                const int t = (n + k) / e.reshape_w, c = (n + k) - t * e.reshape_w;
+                float x = v[k];
+                if (e.row_mode == C1V_ROW_STORE) {
+                    if (t >= e.dst_len) continue;
+                    if (e.act) x *= load_any(e.act, e.act_dtype, (int64_t)b * e.act_bstride + (int64_t)(e.act_off + t * e.act_rowmul) * e.act_cp + c) > 0.0f ? e.act_scale : 0.0f;
+                    if (e.keep) x = e.keep[(int64_t)b * e.sel_bstride + (int64_t)t * e.sel_cp + c] ? x * e.keep_scale : 0.0f;
+                    store_any(e.dst, e.dst_dtype, (int64_t)b * e.dst_bstride + (int64_t)(e.dst_off + t) * e.dst_cp + c, x);
+                } else {   // UNPOOL
+                    if (2 * t + 1 >= e.dst_len) continue;
+                    if (e.act) x *= load_any(e.act, e.act_dtype, (int64_t)b * e.act_bstride + (int64_t)(e.act_off + t * e.act_rowmul) * e.act_cp + c) > 0.0f ? e.act_scale : 0.0f;
+                    const int sidx = e.sel[(int64_t)b * e.sel_bstride + (int64_t)t * e.sel_cp + c] ? 1 : 0;
+                    const int64_t d = (int64_t)b * e.dst_bstride + (int64_t)(e.dst_off + 2 * t) * e.dst_cp + c;
+                    store_any(e.dst, e.dst_dtype, d + (int64_t)sidx * e.dst_cp, x);
+                    store_any(e.dst, e.dst_dtype, d + (int64_t)(1 - sidx) * e.dst_cp, 0.0f);
+                }
+            }
+            continue;
+        }
+        // from here on (t, c) = (u or u/2, n .. n+3): the four channels are contiguous in every buffer involved
+        const int t = pairs ? (u >> 1) : u;
+        const int64_t si = (int64_t)b * e.sel_bstride + (int64_t)t * e.sel_cp + n;
+        float am[4] = {1.f, 1.f, 1.f, 1.f};
+        if (e.act && e.row_mode != C1V_ROW_UP2 && e.row_mode != C1V_ROW_POOL2) {
+            const int64_t ai = (int64_t)b * e.act_bstride + (int64_t)(e.act_off + t * e.act_rowmul) * e.act_cp + n;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) if (k < cnt) am[k] = load_any(e.act, e.act_dtype, ai + k) > 0.0f ? e.act_scale : 0.0f;
+        }
+        if (e.row_mode == C1V_ROW_STORE) {
+            if (u >= e.nrows || t >= e.dst_len) continue;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                v[k] *= am[k];
+                if (e.keep && k < cnt) v[k] = e.keep[si + k] ? v[k] * e.keep_scale : 0.0f;
+            }
+            store4(e, (int64_t)b * e.dst_bstride + (int64_t)(e.dst_off + t) * e.dst_cp + n, v, cnt);
+        } else if (e.row_mode == C1V_ROW_UP2) {
+            if (u >= e.nrows || 2 * t >= e.dst_len) continue;
+            const int64_t d = (int64_t)b * e.dst_bstride + (int64_t)(e.dst_off + 2 * t) * e.dst_cp + n;
+            store4(e, d, v, cnt);
+            if (2 * t + 1 < e.dst_len) store4(e, d + e.dst_cp, v, cnt);
+        } else if (e.row_mode == C1V_ROW_UNPOOL) {
+            if (u >= e.nrows || 2 * t + 1 >= e.dst_len) continue;
+            float hi[4], lo[4];                                  // row 2t and row 2t+1
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const bool s1 = k < cnt ? (e.sel[si + k] != 0) : false;
+                const float x = v[k] * am[k];
+                hi[k] = s1 ? 0.0f : x; lo[k] = s1 ? x : 0.0f;
+            }
+            const int64_t d = (int64_t)b * e.dst_bstride + (int64_t)(e.dst_off + 2 * t) * e.dst_cp + n;
+            store4(e, d, hi, cnt);
+            store4(e, d + e.dst_cp, lo, cnt);
+        } else if (e.row_mode == C1V_ROW_POOL2) {
+            if (t >= e.dst_len || u + 1 >= e.nrows) continue;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const bool s1 = w[k] > v[k];                    // first maximum wins ties
+                float x = s1 ? w[k] : v[k];
+                if (k < cnt) {
+                    if (e.sel) e.sel[si + k] = s1 ? 1 : 0;
+                    if (e.keep) x = e.keep[si + k] ? x * e.keep_scale : 0.0f;
+                }
+                v[k] = x;
+            }
+            store4(e, (int64_t)b * e.dst_bstride + (int64_t)(e.dst_off + t) * e.dst_cp + n, v, cnt);
+        } else {   // PAIRSUM
+            if (t >= e.dst_len) continue;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = ((u < e.nrows ? v[k] : 0.0f) + (u + 1 < e.nrows ? w[k] : 0.0f)) * am[k];
+            store4(e, (int64_t)b * e.dst_bstride + (int64_t)(e.dst_off + t) * e.dst_cp + n, v, cnt);
+        }
+    }
+}
+
+#ifdef NT_STAMP
+// diagnostic build only: cycle stamps of wave 0 of every workgroup (start, after prologue, after K loop, end)
+__device__ unsigned long long nt_dbg[4 * 8192];
+extern "C" int c1v_debug_read_nt(unsigned long long* dst, int n) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(nt_dbg), sizeof(unsigned long long) * n);
+}
+#define NT_T(i) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp[i]) :: "memory"); \
+    __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define NT_T(i) do {} while (0)
+#endif
+
 template <typename T, int BM, int BN, int NS>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(const NtParams p) {
+#ifdef NT_STAMP
+    unsigned long long stamp[4];
+#endif
+    NT_T(0);
     constexpr int WTM = BM / 2, WTN = BN / 2, MI = WTM / 16, NJ = WTN / 16;
     constexpr int A_IT = BM * 8 / 256, B_IT = BN * 8 / 256, LPT = A_IT + B_IT;
     constexpr int STAGE = (BM + BN) * 128;
@@ -162,6 +235,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const NtParams p) {
 #pragma unroll
     for (int s = 0; s < NS - 1; ++s)
         if (s < KT) issue(s);
+    NT_T(1);
 
     for (int kt = 0; kt < KT; ++kt) {
         // tiles issued so far: min(KT, kt + NS - 1); all but the NS-2 youngest must have landed
@@ -185,33 +259,31 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const NtParams p) {
         }
     }
 
-    // epilogue: acc[i][j][r] is C[m0 + wm*WTM + i*16 + (lane>>4)*4 + r][n0 + wn*WTN + j*16 + (lane&15)]
-    const bool pairs = (p.e.row_mode == C1V_ROW_POOL2) || (p.e.row_mode == C1V_ROW_PAIRSUM);
-    const int nb = n0 + wn * WTN + (lane & 15);
+    NT_T(2);
+    // Epilogue through LDS.  acc[i][j][r] is C[m0 + wm*WTM + i*16 + (lane>>4)*4 + r][n0 + wn*WTN + j*16 + (lane&15)]; the
+    // tile is parked in the (now dead) operand ring as fp32 and then walked by a ROLLED loop in which consecutive threads
+    // own consecutive 4-channel groups of a row.  Two reasons: (1) code size -- the per-element epilogue unrolled over
+    // the accumulator registers was ~40 KB of straight-line code executed once per wave, and its instruction-cache
+    // misses cost more than the K loop at this model's shapes (measured with s_memtime stamps: 10-19 k cycles);
+    // (2) stores and mask loads become whole 128-byte row segments instead of 32-byte scraps.
+    constexpr int LDC = BN + 4;
+    float* ct = (float*)smem;
+    __syncthreads();                                   // every wave is done reading the last operand stage
 #pragma unroll
-    for (int i = 0; i < MI; ++i) {
-        const int mb = m0 + wm * WTM + i * 16 + (lane >> 4) * 4;
-        if (pairs) {
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-            for (int r = 0; r < 4; r += 2) {
-                const int m = mb + r;
-                if (m >= p.e.M) continue;
-                const int b = m / p.e.Le, u = m - b * p.e.Le;
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) epi_pair(p.e, b, u, nb + j * 16, acc[i][j][r], acc[i][j][r + 1]);
-            }
-        } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = mb + r;
-                if (m >= p.e.M) continue;
-                const int b = m / p.e.Le, u = m - b * p.e.Le;
-                if (u >= p.e.nrows) continue;
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) epi_row(p.e, b, u, nb + j * 16, acc[i][j][r]);
-            }
-        }
-    }
+            for (int r = 0; r < 4; ++r)
+                ct[(wm * WTM + i * 16 + (lane >> 4) * 4 + r) * LDC + wn * WTN + j * 16 + (lane & 15)] = acc[i][j][r];
+    __syncthreads();
+    epilogue_tile<BM, BN>(p.e, ct, LDC, m0, n0, tid);
+#ifdef NT_STAMP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    NT_T(3);
+    const int wg = blockIdx.x + gridDim.x * blockIdx.y;
+    if (tid == 0 && wg < 8192) for (int i = 0; i < 4; ++i) nt_dbg[wg * 4 + i] = stamp[i];
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------------

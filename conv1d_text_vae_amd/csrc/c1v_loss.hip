@@ -36,8 +36,21 @@ __global__ __launch_bounds__(256) void l2norm_rows_kernel(const float* __restric
 // fused vocabulary stream kernel (bf16)
 // ------------------------------------------------------------------------------------------------------
 enum { VS_ACCUM = 0, VS_SUMEXP = 1, VS_ARGMAX = 2 };
+#ifdef VS_STAMP
+// diagnostic build only: per-segment cycle sums of wave 0 of every workgroup (guide: "In-kernel stamps")
+__device__ unsigned long long vs_dbg[8 * 4096];
+#define VS_T(i) do { __builtin_amdgcn_sched_barrier(0); unsigned long long t_; \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+    seg[i] += t_ - tprev; tprev = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+extern "C" int c1v_debug_read(unsigned long long* dst, int n) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(vs_dbg), sizeof(unsigned long long) * n);
+}
+#else
+#define VS_T(i) do {} while (0)
+#endif
 constexpr int VS_BN = 64;     // vocabulary rows per LDS tile
 constexpr int VS_BM = 128;    // sample rows per workgroup (4 waves x 32)
+constexpr int VS_STAGES = 3;  // LDS ring of vocabulary tiles
 
 template <int CB> struct VsCfg {
     static constexpr int KP = CB * 32;
@@ -49,6 +62,7 @@ template <int CB> struct VsCfg {
     static constexpr int PIECES = STAGE / 1024;                          // 1 KiB LDS-DMA pieces per tile
     static constexpr int PPW = (PIECES + 3) / 4;                         // pieces per wave
     static_assert(STAGE % 1024 == 0, "tile must be whole LDS-DMA pieces");
+    static_assert(PIECES % 4 == 0, "every wave issues the same number of pieces (counted vmcnt waits rely on it)");
     static_assert(PITCH % 256 == 64 || PITCH % 256 == 192, "pitch keeps the transposed reads conflict-free");
 };
 
@@ -63,7 +77,8 @@ void vocab_stream_kernel(const bf16_raw* __restrict__ yhat, int M, const bf16_ra
     using Cfg = VsCfg<CB>;
     constexpr int KS = CB * 2;                     // 16-wide k steps of GEMM1
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, h = lane >> 5;
     const int split = blockIdx.y;
     const int m_row = blockIdx.x * VS_BM + wave * 32 + l31;
@@ -71,7 +86,8 @@ void vocab_stream_kernel(const bf16_raw* __restrict__ yhat, int M, const bf16_ra
     int t_end = t_begin + tiles_per_split;
     if (t_end > tiles_total) t_end = tiles_total;
 
-    // LDS-DMA source offsets of this lane for the pieces of its wave (bytes from the tile's first row)
+    // LDS-DMA source offsets of this lane for the pieces of its wave (bytes from the tile's first row); every wave owns
+    // PPW pieces (PIECES % 4 == 0), so no piece is conditional and counted vmcnt waits are the same in all waves
     int src_off[Cfg::PPW];
 #pragma unroll
     for (int i = 0; i < Cfg::PPW; ++i) {
@@ -79,20 +95,21 @@ void vocab_stream_kernel(const bf16_raw* __restrict__ yhat, int M, const bf16_ra
         const int L = piece * 64 + lane;
         const int r = L / Cfg::CPR, chp = L - r * Cfg::CPR;
         const int ch = chp ^ ((r >> 2) & 3);
-        src_off[i] = (piece < Cfg::PIECES && chp < Cfg::DCH) ? r * Cfg::ROWB + ch * 16 : 0;
+        src_off[i] = (chp < Cfg::DCH) ? r * Cfg::ROWB + ch * 16 : 0;
     }
-    auto stage_tile = [&](int t, int stage) {
+    auto stage_piece = [&](int t, int stage, int i) {
         const char* tile = (const char*)w + (int64_t)t * VS_BN * Cfg::ROWB;
+        c1v_glds16(tile + src_off[i], c1v_lds_addr(smem + stage * Cfg::STAGE + (wave + 4 * i) * 1024));
+    };
+    auto stage_tile = [&](int t, int stage) {
 #pragma unroll
-        for (int i = 0; i < Cfg::PPW; ++i) {
-            const int piece = wave + 4 * i;
-            if (piece < Cfg::PIECES)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(tile + src_off[i]),
-                                                 C1V_LDS_PTR(void, smem + stage * Cfg::STAGE + piece * 1024), 16, 0, 0);
-        }
+        for (int i = 0; i < Cfg::PPW; ++i) stage_piece(t, stage, i);
     };
 
+    // three LDS stages: tile t+2 is requested when tile t starts, so a request has two tile times to arrive (with two
+    // stages the L2/fabric latency of a 44 KiB request, not the MFMA work, set the tile time)
     if (t_begin < t_end) stage_tile(t_begin, 0);
+    if (t_begin + 1 < t_end) stage_tile(t_begin + 1, 1);
 
     // this wave's 32 sample rows as MFMA B operands: B[k = 8h + j][col = l31] = yhat[m_row][16 s + 8h + j]
     bf16x8_t yf[KS];
@@ -114,84 +131,180 @@ void vocab_stream_kernel(const bf16_raw* __restrict__ yhat, int M, const bf16_ra
     float best = -3.0e38f;
     int best_idx = 0x7fffffff;
 
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // Both requests and the yf loads (one-time cost).  The BUILTIN form on purpose: the compiler's own bookkeeping must
+    // see that the yf loads are complete, or it keeps a `vmcnt(0)` in front of the first MFMA of EVERY tile (an asm wait
+    // is invisible to it), which waits for the LDS-DMA request issued a few instructions earlier.
+    __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0), expcnt / lgkmcnt untouched
+    asm volatile("" ::: "memory");
     __syncthreads();
 
-    for (int t = t_begin; t < t_end; ++t) {
-        const int stage = (t - t_begin) & 1;
-        if (t + 1 < t_end) stage_tile(t + 1, stage ^ 1);
-        const char* sw = smem + stage * Cfg::STAGE;
-        const int n0 = t * VS_BN;
+    // Software pipeline of one tile (one wave per SIMD, so nothing else hides LDS latency): operand fragments are
+    // fetched one BATCH ahead into a second register buffer, and the VALU work on a finished accumulator block is
+    // issued inside the MFMA groups of the next block:
+    //   GEMM1 nb=0 | GEMM1 nb=1 + exp2(S0) | GEMM2 nb=0 + exp2(S1) | GEMM2 nb=1
+    // sched_barrier(0) pins "loads of batch q+1, then MFMAs of batch q" (the compiler otherwise re-serialises every
+    // ds_read behind an lgkmcnt(0) in front of its MFMA, which tripled the tile time).
+    constexpr int G1 = (KS % 5 == 0) ? 5 : KS;          // GEMM1 fragments per batch
+    constexpr int NB1 = KS / G1, Q1 = 2 * NB1;
+    constexpr int CG = (CB % 2 == 0) ? 2 : 1;           // GEMM2: cb blocks per batch (2 k-steps each)
+    constexpr int NB2 = CB / CG, Q2 = 2 * NB2;
+    const int tq = (lane & 15) >> 2, tpq = lane & 3, tcg = (lane >> 4) & 1;
 
-        // GEMM1: S[nb][reg] = logit of vocabulary row n0 + nb*32 + (reg&3) + 8*(reg>>2) + 4h, sample row m_row
+#ifdef VS_STAMP
+    unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev) :: "memory");
+    const unsigned long long tstart = tprev;
+#endif
+    for (int t = t_begin; t < t_end; ++t) {
+        VS_T(7);
+        const int stage = (t - t_begin) % VS_STAGES;
+#if defined(VS_ABLATE) && (VS_ABLATE & 8)
+        const char* sw = smem;
+#else
+        const bool more = t + 2 < t_end;            // wave-uniform: tile t+2 is requested inside GEMM1 below
+        const char* sw = smem + stage * Cfg::STAGE;
+#endif
+        const int n0 = t * VS_BN;
+        const bool tail = n0 + VS_BN > N;
+
+        auto ld1 = [&](int nb, int s) -> uint4 { return *(const uint4*)(sw + vs_off<CB>(nb * 32 + l31, 2 * s + h)); };
+        // W^T fragment of GEMM2: k slot (h, j) of step (nb, ks) is vocabulary row nb*32 + 16ks + 8(j>>2) + 4h + (j&3),
+        // exactly the accumulator rows held in regs 8ks..8ks+7 of S[nb]
+        auto ld2 = [&](int nb, int ks, int cb) -> uint4 {
+            const int chunk = cb * 4 + 2 * tcg + (tpq >> 1);
+            const int sub = 8 * (tpq & 1);
+            const int r0 = nb * 32 + 16 * ks + 4 * h + tq;
+            s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(C1V_LDS_PTR(s16x4_t, sw + vs_off<CB>(r0, chunk) + sub));
+            s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(C1V_LDS_PTR(s16x4_t, sw + vs_off<CB>(r0 + 8, chunk) + sub));
+            return make_uint4(__builtin_bit_cast(uint2, lo).x, __builtin_bit_cast(uint2, lo).y,
+                              __builtin_bit_cast(uint2, hi).x, __builtin_bit_cast(uint2, hi).y);
+        };
+
         f32x16_t S[2];
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb) {
+        for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) S[nb][r] = 0.f;
-#pragma unroll
-            for (int s = 0; s < KS; ++s) {
-                const uint4 a = *(const uint4*)(sw + vs_off<CB>(nb * 32 + l31, 2 * s + h));
-                S[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), yf[s], S[nb], 0, 0, 0);
-            }
-        }
 
-        if constexpr (MODE == VS_ARGMAX) {
+        // VALU stage on accumulator regs [r0, r1) of block nb: exp2 (+ tail mask) / running sum / running arg-max
+        auto post = [&](int nb, int r0, int r1) {
 #pragma unroll
-            for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
+            for (int r = r0; r < r1; ++r) {
+                if constexpr (MODE == VS_ARGMAX) {
                     const int n = n0 + nb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                     const float v = S[nb][r];
                     if (n < N && v > best) { best = v; best_idx = n; }
-                }
-        } else {
-            const bool tail = n0 + VS_BN > N;
-#pragma unroll
-            for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
+                } else {
+#if defined(VS_ABLATE) && (VS_ABLATE & 1)
+                    float e = S[nb][r];
+#else
                     float e = __builtin_amdgcn_exp2f(S[nb][r]);
-                    if (tail) { const int n = n0 + nb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h; if (n >= N) e = 0.f; }
+#endif
+                    if constexpr (MODE == VS_SUMEXP) {
+                        // (ACCUM needs no tail mask: rows >= N of W are all-zero, ones column included, so whatever
+                        // exp2 gives for them is multiplied by zero in GEMM2)
+                        if (tail) { const int n = n0 + nb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h; if (n >= N) e = 0.f; }
+                        sumexp += e;
+                    }
                     S[nb][r] = e;
                 }
-            if constexpr (MODE == VS_SUMEXP) {
+            }
+        };
+
+        uint4 a1[2][G1];
+        uint4 a2[3][CG * 2];
 #pragma unroll
-                for (int nb = 0; nb < 2; ++nb)
+        for (int j = 0; j < G1; ++j) a1[0][j] = ld1(0, j);
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) sumexp += S[nb][r];
-            } else {
-                // GEMM2: U^T[c][m] += sum_n W[n][c] * E[n][m]; k slot (h, j) of step (nb, ks) is vocabulary row
-                // nb*32 + 16ks + 8(j>>2) + 4h + (j&3): exactly the accumulator rows held in regs 8ks..8ks+7.
-                bf16x8_t pf[2][2];
+        for (int q = 0; q < Q1; ++q) {
+            const int nb = q / NB1, s0 = (q % NB1) * G1;
+            if (q + 1 < Q1) {
+                const int nb2 = (q + 1) / NB1, s2 = ((q + 1) % NB1) * G1;
 #pragma unroll
-                for (int nb = 0; nb < 2; ++nb)
+                for (int j = 0; j < G1; ++j) a1[(q + 1) & 1][j] = ld1(nb2, s2 + j);
+            } else if constexpr (MODE == VS_ACCUM) {
+#pragma unroll
+                for (int qq = 0; qq < 2 && qq < Q2; ++qq)
+#pragma unroll
+                    for (int c = 0; c < CG; ++c)
+#pragma unroll
+                        for (int ks = 0; ks < 2; ++ks) a2[qq][c * 2 + ks] = ld2(qq / NB2, ks, (qq % NB2) * CG + c);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < G1; ++j) {
+#if defined(VS_ABLATE) && (VS_ABLATE & 4)
+                if (j == 0 && s0 == 0)
+#endif
+                S[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a1[q & 1][j]), yf[s0 + j], S[nb], 0, 0, 0);
+            }
+#if !(defined(VS_ABLATE) && (VS_ABLATE & 8))
+            // the request for tile t+2 goes out in the shadow of the nb=0 MFMAs (its stage was released by the barrier
+            // that ended tile t-1), a few pieces per batch
+            if (nb == 0 && more) {
+#pragma unroll
+                for (int i = q * Cfg::PPW / NB1; i < (q + 1) * Cfg::PPW / NB1; ++i) stage_piece(t + 2, (stage + 2) % VS_STAGES, i);
+            }
+#endif
+            if (nb == 1) post(0, (q - NB1) * 16 / NB1, (q - NB1 + 1) * 16 / NB1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (q == NB1 - 1) VS_T(0);
+            if (q == Q1 - 1) VS_T(1);
+        }
+
+        if constexpr (MODE != VS_ACCUM) {
+            post(1, 0, 16);
+        } else {
+            bf16x8_t pf[2][2];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pf[0][ks][j] = (__bf16)S[0][8 * ks + j];
+#pragma unroll
+            for (int q = 0; q < Q2; ++q) {
+                const int nb = q / NB2, cb0 = (q % NB2) * CG;
+                if (q + 2 < Q2) {
+                    const int nb2 = (q + 2) / NB2, cb2 = ((q + 2) % NB2) * CG;
+#pragma unroll
+                    for (int c = 0; c < CG; ++c)
+#pragma unroll
+                        for (int ks = 0; ks < 2; ++ks) a2[(q + 2) % 3][c * 2 + ks] = ld2(nb2, ks, cb2 + c);
+                }
+                if (q == NB2) {
 #pragma unroll
                     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) pf[nb][ks][j] = (__bf16)S[nb][8 * ks + j];
-                const int q = (lane & 15) >> 2, pq = lane & 3, cg = (lane >> 4) & 1;
-#pragma unroll
-                for (int cb = 0; cb < CB; ++cb) {
-                    const int chunk = cb * 4 + 2 * cg + (pq >> 1);
-                    const int sub = 8 * (pq & 1);
-#pragma unroll
-                    for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-                        for (int ks = 0; ks < 2; ++ks) {
-                            const int r0 = nb * 32 + 16 * ks + 4 * h + q;
-                            s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(C1V_LDS_PTR(s16x4_t, sw + vs_off<CB>(r0, chunk) + sub));
-                            s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(C1V_LDS_PTR(s16x4_t, sw + vs_off<CB>(r0 + 8, chunk) + sub));
-                            const uint4 a = make_uint4(__builtin_bit_cast(uint2, lo).x, __builtin_bit_cast(uint2, lo).y,
-                                                       __builtin_bit_cast(uint2, hi).x, __builtin_bit_cast(uint2, hi).y);
-                            U[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), pf[nb][ks], U[cb], 0, 0, 0);
-                        }
+                        for (int j = 0; j < 8; ++j) pf[1][ks][j] = (__bf16)S[1][8 * ks + j];
                 }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int c = 0; c < CG; ++c)
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks)
+#if defined(VS_ABLATE) && (VS_ABLATE & 2)
+                        if (cb0 + c == 0)
+#endif
+                        U[cb0 + c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a2[q % 3][c * 2 + ks]), pf[nb][ks],
+                                                                             U[cb0 + c], 0, 0, 0);
+                if (nb == 0) post(1, q * 16 / NB2, (q + 1) * 16 / NB2);
+                __builtin_amdgcn_sched_barrier(0);
+                if (q == NB2 - 1) VS_T(2);
+                if (q == Q2 - 1) VS_T(3);
             }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#if !(defined(VS_ABLATE) && (VS_ABLATE & 8))
+        // tile t+1 must have landed; tile t+2's request (the youngest PPW loads of this wave) stays in flight
+        if (t + 2 < t_end) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Cfg::PPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        VS_T(4);
         __syncthreads();
+        VS_T(5);
+#endif
     }
+#ifdef VS_STAMP
+    unsigned long long tloop;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tloop) :: "memory");
+#endif
 
     const int m_out = blockIdx.x * VS_BM + wave * 32 + l31;
     if constexpr (MODE == VS_ACCUM) {
@@ -225,6 +338,18 @@ void vocab_stream_kernel(const bf16_raw* __restrict__ yhat, int M, const bf16_ra
             part_idx[(int64_t)split * m_pad + m_out] = best_idx == 0x7fffffff ? 0x7fffffff : best_idx + n_base;
         }
     }
+#ifdef VS_STAMP
+    if (tid == 0) {
+        unsigned long long tend;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tend) :: "memory");
+        const int wg = blockIdx.x + gridDim.x * blockIdx.y;
+        if (wg < 4096) {
+            for (int i = 0; i < 6; ++i) vs_dbg[wg * 8 + i] = seg[i];
+            vs_dbg[wg * 8 + 6] = tloop - tstart;
+            vs_dbg[wg * 8 + 7] = tend - tloop;
+        }
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -422,12 +547,12 @@ template <int CB, int MODE>
 static int launch_vs(const bf16_raw* yhat, int M, const bf16_raw* w, int N, int n_base, int splits, float* ut, int m_pad, int ones_col,
                      float* ps, int* pi, hipStream_t st) {
     using Cfg = VsCfg<CB>;
-    static bool once = (hipFuncSetAttribute((const void*)vocab_stream_kernel<CB, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * Cfg::STAGE), true);
+    static bool once = (hipFuncSetAttribute((const void*)vocab_stream_kernel<CB, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, VS_STAGES * Cfg::STAGE), true);
     (void)once;
     const int tiles_total = (int)c1v_cdiv(N, VS_BN);
     const int tps = (int)c1v_cdiv(tiles_total, splits);
     dim3 grid((unsigned)(m_pad / VS_BM), (unsigned)splits);
-    hipLaunchKernelGGL((vocab_stream_kernel<CB, MODE>), grid, dim3(256), 2 * Cfg::STAGE, st, yhat, M, w, N, n_base, tiles_total, tps, ut, m_pad, ones_col, ps, pi);
+    hipLaunchKernelGGL((vocab_stream_kernel<CB, MODE>), grid, dim3(256), VS_STAGES * Cfg::STAGE, st, yhat, M, w, N, n_base, tiles_total, tps, ut, m_pad, ones_col, ps, pi);
     C1V_LAUNCH_CHECK();
     return 0;
 }

@@ -17,6 +17,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from typing import Dict, List, Optional
 
 import numpy as np
@@ -245,7 +246,7 @@ class VAEEngine:
         fused = self.code == L.BF16 and self.kp in (32, 64, 320)
         tiles = self.n_pad // 64
         if fused:
-            want = max(1, (2 * 256) // max(1, self.m_pad // 128))
+            want = max(1, (int(os.environ.get('C1V_WG_WAVES', '2')) * 256) // max(1, self.m_pad // 128))
             self.x_splits = max(1, min(tiles, want, 16))
             self.n_chunk = 0
             self.logits = None
