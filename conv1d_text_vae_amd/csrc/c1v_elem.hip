@@ -6,32 +6,48 @@
 // ------------------------------------------------------------------------------------------------------
 // input packing
 // ------------------------------------------------------------------------------------------------------
+// one thread per (row, group of 8 padded channels): 8 coalesced fp32 reads, one 16- / 32-byte store (zeros in the padding)
+template <typename T>
+__device__ __forceinline__ void store8(c1v_seq dst, int64_t idx, const float v[8]) {
+    if constexpr (sizeof(T) == 2) {
+        *(uint4*)((bf16_raw*)dst.data + idx) = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+    } else {
+        float4* d = (float4*)((float*)dst.data + idx);
+        d[0] = make_float4(v[0], v[1], v[2], v[3]); d[1] = make_float4(v[4], v[5], v[6], v[7]);
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void pack_input_kernel(const float* __restrict__ src, int T_len, int C, c1v_seq dst) {
-    // one thread per (row, padded channel): writes zeros into the channel padding as well
-    const int64_t total = (int64_t)dst.batch * T_len * dst.cp;
+    const int g8 = dst.cp >> 3;
+    const int64_t total = (int64_t)dst.batch * T_len * g8;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int c = (int)(i % dst.cp);
-        const int64_t row = i / dst.cp;
+        const int c0 = (int)(i % g8) * 8;
+        const int64_t row = i / g8;
         const int t = (int)(row % T_len);
         const int64_t b = row / T_len;
-        const float v = c < C ? src[row * C + c] : 0.0f;
-        ElemTraits<T>::store(dst.data, b * dst.bstride + (int64_t)(dst.off + t) * dst.cp + c, v);
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = c0 + k < C ? src[row * C + c0 + k] : 0.0f;
+        store8<T>(dst, b * dst.bstride + (int64_t)(dst.off + t) * dst.cp + c0, v);
     }
 }
 
 template <typename T>
 __global__ __launch_bounds__(256) void gather_input_kernel(const float* __restrict__ table, int64_t ld, const int* __restrict__ ids,
                                                            int T_len, int C, c1v_seq dst) {
-    const int64_t total = (int64_t)dst.batch * T_len * dst.cp;
+    const int g8 = dst.cp >> 3;
+    const int64_t total = (int64_t)dst.batch * T_len * g8;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int c = (int)(i % dst.cp);
-        const int64_t row = i / dst.cp;
+        const int c0 = (int)(i % g8) * 8;
+        const int64_t row = i / g8;
         const int t = (int)(row % T_len);
         const int64_t b = row / T_len;
         const int id = ids[row];
-        const float v = (c < C && id >= 0) ? table[(int64_t)id * ld + c] : 0.0f;
-        ElemTraits<T>::store(dst.data, b * dst.bstride + (int64_t)(dst.off + t) * dst.cp + c, v);
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = (c0 + k < C && id >= 0) ? table[(int64_t)id * ld + c0 + k] : 0.0f;
+        store8<T>(dst, b * dst.bstride + (int64_t)(dst.off + t) * dst.cp + c0, v);
     }
 }
 
@@ -52,7 +68,8 @@ extern "C" int c1v_pack_input(const c1v_pack_input_args* a, void* stream) {
     C1V_REQUIRE(a && a->src, "pack_input: null argument");
     if (check_seq(a->dst, "pack_input dst")) return -1;
     C1V_REQUIRE(a->T > 0 && a->T <= a->dst.len && a->C > 0 && a->C <= a->dst.cp, "pack_input: shape mismatch (T=%d C=%d)", a->T, a->C);
-    const int64_t total = (int64_t)a->dst.batch * a->T * a->dst.cp;
+    C1V_REQUIRE(a->dst.cp % 8 == 0 && a->dst.bstride % 8 == 0 && ((uintptr_t)a->dst.data % 32) == 0, "pack_input: dst rows must be 8-element groups, 32-byte aligned");
+    const int64_t total = (int64_t)a->dst.batch * a->T * (a->dst.cp / 8);
     if (a->dst.dtype == C1V_F32) hipLaunchKernelGGL(pack_input_kernel<float>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, a->src, a->T, a->C, a->dst);
     else hipLaunchKernelGGL(pack_input_kernel<bf16_raw>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, a->src, a->T, a->C, a->dst);
     C1V_LAUNCH_CHECK();
@@ -63,7 +80,8 @@ extern "C" int c1v_gather_input(const c1v_gather_input_args* a, void* stream) {
     C1V_REQUIRE(a && a->table && a->ids, "gather_input: null argument");
     if (check_seq(a->dst, "gather_input dst")) return -1;
     C1V_REQUIRE(a->T > 0 && a->T <= a->dst.len && a->C > 0 && a->C <= a->dst.cp && a->ld >= a->C, "gather_input: shape mismatch");
-    const int64_t total = (int64_t)a->dst.batch * a->T * a->dst.cp;
+    C1V_REQUIRE(a->dst.cp % 8 == 0 && a->dst.bstride % 8 == 0 && ((uintptr_t)a->dst.data % 32) == 0, "gather_input: dst rows must be 8-element groups, 32-byte aligned");
+    const int64_t total = (int64_t)a->dst.batch * a->T * (a->dst.cp / 8);
     if (a->dst.dtype == C1V_F32) hipLaunchKernelGGL(gather_input_kernel<float>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, a->table, a->ld, a->ids, a->T, a->C, a->dst);
     else hipLaunchKernelGGL(gather_input_kernel<bf16_raw>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, a->table, a->ld, a->ids, a->T, a->C, a->dst);
     C1V_LAUNCH_CHECK();
@@ -74,24 +92,44 @@ extern "C" int c1v_gather_input(const c1v_gather_input_args* a, void* stream) {
 // weight operand copies (descriptor table on the device; blockIdx.y = descriptor)
 // ------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void pack_weights_kernel(const c1v_pack_desc* __restrict__ descs, int n_desc) {
-    // blocks are dealt to descriptors by their `first_block`; one block copies C1V_CHUNK consecutive destination elements
+    // One block = one 32(c) x 32(n) tile of one tap of one descriptor, transposed through LDS so that BOTH the fp32 read
+    // (along whichever of n / c is contiguous in the Keras layout) and the operand write (along c) are whole row
+    // segments.  Blocks are dealt to descriptors by `first_block`; within a descriptor the tile index enumerates
+    // (tap, c tile, n tile).
+    __shared__ float tile[32][33];
     int di = 0;
     while (di + 1 < n_desc && (int)blockIdx.x >= descs[di + 1].first_block) ++di;
     const c1v_pack_desc d = descs[di];
-    const int64_t total = (int64_t)d.n_count * d.taps * d.c_count;
-    const int64_t base = (int64_t)((int)blockIdx.x - d.first_block) * C1V_CHUNK;
+    const int tc = (d.c_count + 31) >> 5, tn = (d.n_count + 31) >> 5;
+    int bi = (int)blockIdx.x - d.first_block;
+    const int tn_i = bi % tn; bi /= tn;
+    const int tc_i = bi % tc;
+    const int tap = bi / tc;
+    if (tap >= d.taps) return;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 8
+    const int c0 = tc_i * 32, n0 = tn_i * 32;
+    const float* src = d.src + (int64_t)tap * d.s_tap;
+    if (d.s_n <= d.s_c) {
+        // n is the fast axis of the source: read rows of n, tile[c][n]
 #pragma unroll
-    for (int k = 0; k < C1V_CHUNK / 256; ++k) {
-        const int64_t i = base + k * 256 + threadIdx.x;
-        if (i >= total) break;
-        // destination-major enumeration (n, tap', c) -> coalesced writes
-        const int c = (int)(i % d.c_count);
-        const int64_t r = i / d.c_count;
-        const int tp = (int)(r % d.taps);
-        const int n = (int)(r / d.taps);
-        const int tap = d.flip ? d.taps - 1 - tp : tp;
-        const float v = d.src[(int64_t)tap * d.s_tap + (int64_t)c * d.s_c + (int64_t)n * d.s_n];
-        store_any(d.dst, d.dtype, (int64_t)n * d.ldk + (int64_t)tp * d.cp + c, v);
+        for (int k = 0; k < 4; ++k) {
+            const int c = c0 + ty + 8 * k, n = n0 + tx;
+            tile[ty + 8 * k][tx] = (c < d.c_count && n < d.n_count) ? src[(int64_t)c * d.s_c + (int64_t)n * d.s_n] : 0.0f;
+        }
+    } else {
+        // c is the fast axis of the source: read rows of c
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int n = n0 + ty + 8 * k, c = c0 + tx;
+            tile[tx][ty + 8 * k] = (c < d.c_count && n < d.n_count) ? src[(int64_t)c * d.s_c + (int64_t)n * d.s_n] : 0.0f;
+        }
+    }
+    __syncthreads();
+    const int tp = d.flip ? d.taps - 1 - tap : tap;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int n = n0 + ty + 8 * k, c = c0 + tx;
+        if (c < d.c_count && n < d.n_count) store_any(d.dst, d.dtype, (int64_t)n * d.ldk + (int64_t)tp * d.cp + c, tile[tx][ty + 8 * k]);
     }
 }
 

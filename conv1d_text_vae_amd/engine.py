@@ -246,7 +246,7 @@ class VAEEngine:
         fused = self.code == L.BF16 and self.kp in (32, 64, 320)
         tiles = self.n_pad // 64
         if fused:
-            want = max(1, (int(os.environ.get('C1V_WG_WAVES', '2')) * 256) // max(1, self.m_pad // 128))
+            want = max(1, (int(os.environ.get('C1V_WG_WAVES', '1')) * 256) // max(1, self.m_pad // 128))
             self.x_splits = max(1, min(tiles, want, 16))
             self.n_chunk = 0
             self.logits = None
@@ -281,7 +281,7 @@ class VAEEngine:
             self.wld[key] = ldk
             descs.append(L.PackDesc(self._pslice(src_name), t.data_ptr(), self.code, n_count, taps, c_count, cp, flip,
                                     ldk, s_tap, s_c, s_n, nblk[0], 0))
-            nblk[0] += (n_count * taps * c_count + L.CHUNK - 1) // L.CHUNK
+            nblk[0] += taps * ((c_count + 31) // 32) * ((n_count + 31) // 32)
 
         c_in = g.input_vector_size
         for l, f in enumerate(g.n_filters):

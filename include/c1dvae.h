@@ -152,7 +152,8 @@ typedef struct c1v_pack_desc {
     const float* src; void* dst; int32_t dtype;
     int32_t n_count, taps, c_count, cp, flip;
     int64_t ldk, s_tap, s_c, s_n;
-    int32_t first_block, pad;   /* descriptor i owns blocks [first_block_i, first_block_{i+1}): ceil(elements / C1V_CHUNK) each */
+    int32_t first_block, pad;   /* descriptor i owns blocks [first_block_i, first_block_{i+1}): taps * ceil(c_count/32) * ceil(n_count/32)
+                                 * each (one block = one 32x32 tile of one tap, transposed through LDS) */
 } c1v_pack_desc;
 #define C1V_CHUNK 2048          /* elements handled by one block of the descriptor-table kernels */
 /* `descs` is a DEVICE array of n_desc descriptors (ascending first_block); total_blocks = sum of their block counts */
