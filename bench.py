@@ -23,6 +23,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 CFG = dict(batch=256, seq_len=32, emb=300, n_filters=(128,), kernel_size=3, latent=256, vocab_rows=8192)
+# BASELINE.json configs[2]: transform()/predict() inference, batch 8192, seq_len 64, 200k-word vocabulary
+CFG_PREDICT = dict(batch=8192, seq_len=64, emb=300, n_filters=(128,), kernel_size=3, latent=256, vocab_words=200000)
 BF16_DENSE_PEAK_TFLOPS = 2500.0       # /opt/skills/guides/MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
 
 
@@ -87,6 +89,54 @@ def cpu_baseline(seconds_budget=20.0):
                        '(CPU restatement of the reference arithmetic, not Keras)' % timed)
 
 
+def predict_leg(dev, dtype, steps=3):
+    """Secondary metric of BASELINE.json ("predict sentences/sec"): encoder -> decoder -> EOS truncation -> nearest
+    vocabulary word of every reconstructed step (fused MFMA GEMM + arg-max) on the C3 shapes, excluding tokenisation and
+    the character-level generator stage.  Inputs resident in HBM."""
+    import numpy as np
+    import torch
+    from conv1d_text_vae_amd import engine, geometry, synthetic
+    c = CFG_PREDICT
+    V = c['emb'] + 2
+    B, T = c['batch'], c['seq_len']
+    g = geometry.Geometry(T, T, V, V, c['n_filters'], c['kernel_size'], c['latent'])
+    rng = np.random.Generator(np.random.PCG64(99))
+    words = rng.standard_normal((c['vocab_words'], c['emb']), dtype=np.float32)
+    words /= np.linalg.norm(words, axis=1, keepdims=True)
+    eng = engine.VAEEngine(g, B, None, dtype=dtype, device=dev, seed=7)
+    dec = engine.VocabDecoder(words, B * T, dtype=dtype, device=dev)
+    x = np.zeros((B, T, V), dtype=np.float32)
+    ids = rng.integers(0, c['vocab_words'], size=(B, T - 1))
+    x[:, :T - 1, :c['emb']] = words[ids]
+    x[:, T - 1, V - 1] = 1.0
+    eng.load_batch(x=x)
+    del x
+
+    def step():
+        post = eng.reconstruct(postprocess=True)                      # [B, T, V-1] fp32, one captured HIP graph
+        dec.load_rows_normalized(post, V - 1)
+        return dec.run()
+
+    step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    flops = 2.0 * B * T * c['emb'] * c['vocab_words']
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    dec.run()
+    e1.record()
+    torch.cuda.synchronize()
+    k_ms = e0.elapsed_time(e1)
+    return {'metric': 'predict_sentences_per_sec', 'value': B / dt, 'unit': 'sentences/s', 'ms_per_batch': dt * 1e3,
+            'workload': 'C3: batch 8192, seq_len 64, emb 300, 200000-word vocabulary, encoder+decoder+EOS truncation+'
+                        'nearest-word GEMM/arg-max (no tokenisation, no character generator)',
+            'vocab_argmax_ms': k_ms, 'vocab_argmax_tflops': flops / (k_ms * 1e-3) / 1e12}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -94,8 +144,19 @@ def main():
     ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-predict', action='store_true', help='skip the secondary predict-throughput measurement')
+    ap.add_argument('--traffic', type=float, default=None,
+                    help='HBM bytes per launch of the dominant kernel from a separate rocprofv3 --pmc pass (see profiles/)')
     ap.add_argument('--kernel-only', action='store_true', help='only loop the dominant kernel (for rocprofv3 --pmc passes)')
     args = ap.parse_args()
+    if args.traffic is None:
+        # HBM bytes per launch of the dominant kernel come from SEPARATE rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE;
+        # gfx950 correction: FETCH_SIZE counts half of a wide streaming read) whose summary is committed under profiles/
+        pmc = os.path.join(ROOT, 'profiles', 'r01_c_pmc_vocab_stream.json')
+        if os.path.isfile(pmc):
+            with open(pmc) as fp:
+                c = json.load(fp)['per_launch_avg']
+            args.traffic = (2.0 * c['FETCH_SIZE'] + c['WRITE_SIZE']) * 1024.0
 
     import numpy as np
     import torch
@@ -182,8 +243,12 @@ def main():
                          'achieved': achieved, 'peak': BF16_DENSE_PEAK_TFLOPS if args.dtype == 'bf16' else 157.3,
                          'unit': 'TFLOP/s',
                          'frac': achieved / (BF16_DENSE_PEAK_TFLOPS if args.dtype == 'bf16' else 157.3),
-                         'traffic': None, 'kernel_ms': k_ms, 'flops_per_launch': loss_flops},
+                         'traffic': args.traffic, 'kernel_ms': k_ms, 'flops_per_launch': loss_flops},
         }
+        if world == 1 and not args.no_predict:
+            del eng
+            torch.cuda.empty_cache()
+            out['predict'] = predict_leg(dev, args.dtype)
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()
         print(json.dumps(out))

@@ -805,6 +805,16 @@ class VocabDecoder:
         qv[:M, :self.K].copy_(q.to(self.dev))
         self.M = M
 
+    def load_rows_normalized(self, rows: torch.Tensor, ld: int):
+        """Queries straight from device rows (e.g. the post-processed decoder output [M, ld] fp32): the first K features of
+        every row, L2-normalised by c1v_l2norm_rows (find_best_words :584-587), land in the operand buffer.  No host copy."""
+        M = rows.numel() // ld
+        if M > self.Mmax or ld < self.K:
+            raise ValueError('rows must be [<= {0}, >= {1}]'.format(self.Mmax, self.K))
+        a = L.L2NormArgs(rows.data_ptr(), M, self.K, ld, self.q.data_ptr(), self.code, self.kp, None, 1.0)
+        L.call('c1v_l2norm_rows', C.byref(a), C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream))
+        self.M = M
+
     def run(self):
         a = L.VocabArgmaxArgs(self.q.data_ptr(), self.code, self.M, self.kp, self.w.data_ptr(), self.N, self.n_pad,
                               self.n_base, self.part_score.data_ptr(), self.part_idx.data_ptr(), self.m_pad, self.splits,
