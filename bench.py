@@ -147,6 +147,8 @@ def main():
     ap.add_argument('--no-predict', action='store_true', help='skip the secondary predict-throughput measurement')
     ap.add_argument('--traffic', type=float, default=None,
                     help='HBM bytes per launch of the dominant kernel from a separate rocprofv3 --pmc pass (see profiles/)')
+    ap.add_argument('--force-dp-path', action='store_true',
+                    help='rehearse the multi-rank step sequence (3 graphs + 2 bucketed RCCL all-reduces) at any world size')
     ap.add_argument('--kernel-only', action='store_true', help='only loop the dominant kernel (for rocprofv3 --pmc passes)')
     args = ap.parse_args()
     if args.traffic is None:
@@ -172,8 +174,10 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = 'cuda:%d' % local_rank
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dp_path:
         import torch.distributed as dist
+        if args.force_dp_path and 'RANK' not in os.environ:
+            os.environ.update(RANK='0', WORLD_SIZE='1', MASTER_ADDR='127.0.0.1', MASTER_PORT='29533')
         dist.init_process_group('nccl', device_id=torch.device(dev))
 
     V = CFG['emb'] + 2
@@ -181,12 +185,14 @@ def main():
     W = synthetic.synthetic_vocab(CFG['vocab_rows'] - 2, CFG['emb'])
     B = CFG['batch']
     x, ids = synthetic.synthetic_batch(W, W.shape[0], B * world, CFG['seq_len'], CFG['seq_len'])
-    eng = engine.VAEEngine(g, B, W, dtype=args.dtype, device=dev, seed=1234, world_size=world, rank=rank)
+    eng = engine.VAEEngine(g, B, W, dtype=args.dtype, device=dev, seed=1234, world_size=world, rank=rank,
+                           force_bucketed=args.force_dp_path)
     eng.load_batch(x[rank * B:(rank + 1) * B], ids[rank * B:(rank + 1) * B])      # inputs resident in HBM
     torch.cuda.synchronize()
 
     def all_reduce(t):
-        dist.all_reduce(t)
+        # RCCL sum of one gradient bucket; asynchronous, so the next graph replays while the bucket is on the wire
+        return dist.all_reduce(t, async_op=True)
 
     def sync():
         torch.cuda.synchronize()

@@ -71,7 +71,7 @@ class VAEEngine:
     def __init__(self, geom: Geometry, batch: int, vocab_vectors: Optional[np.ndarray] = None, dtype: str = 'bf16',
                  device: str = 'cuda:0', seed: int = 0, world_size: int = 1, rank: int = 0,
                  frozen_encoder: bool = False, weights: Optional[Dict[str, np.ndarray]] = None,
-                 std_scale: float = 1.0):
+                 std_scale: float = 1.0, force_bucketed: bool = False):
         if not torch.cuda.is_available():
             raise L.C1VError('VAEEngine needs a GPU: the HIP kernels are the only implementation of this path.')
         self.lib = L.load()
@@ -85,6 +85,7 @@ class VAEEngine:
             raise ValueError('dtype must be bf16 or f32')
         self.code = L.BF16 if dtype == 'bf16' else L.F32
         self.frozen = bool(frozen_encoder)
+        self.force_bucketed = bool(force_bucketed)      # take the multi-rank step sequence even at world_size 1 (rehearsal)
         self.seed = int(seed)
         self.std_scale = float(std_scale)
         self._keep = []        # python objects that must outlive the captured graphs
@@ -447,6 +448,7 @@ class VAEEngine:
 
         # ---- backward
         segs: List[L.SegDesc] = []
+        seg_names: List[str] = []
         self.slabs: Dict[str, torch.Tensor] = {}
 
         fblk = [0]
@@ -456,6 +458,7 @@ class VAEEngine:
             t = torch.zeros(splits * count, dtype=torch.float32, device=self.dev)
             self.slabs[name] = t
             segs.append(L.SegDesc(t.data_ptr(), count, splits, 1, 0, self.seg_off[name], count, 1 if frozen else 0, fblk[0]))
+            seg_names.append(name)
             fblk[0] += (count + L.CHUNK - 1) // L.CHUNK
             return t
 
@@ -544,19 +547,44 @@ class VAEEngine:
         self.side_stream = torch.cuda.Stream(self.dev)
 
         # ---- optimizer
-        arr = (L.SegDesc * len(segs))(*segs)
-        self.seg_descs = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.dev)
-        self.n_seg = len(segs)
-        self.fin_blocks = fblk[0]
-        self.sq_partial = torch.zeros(max(self.fin_blocks, 256), dtype=torch.float32, device=self.dev)
         f_fin = self.lib.c1v_grad_finalize
         f_sq = self.lib.c1v_sqnorm_partial
         f_adv = self.lib.c1v_nadam_advance
-        n_partial = self.fin_blocks if self.world == 1 else 256
 
-        def finalize():
-            L.check(f_fin(self.seg_descs.data_ptr(), self.n_seg, self.fin_blocks, self.grads.data_ptr(),
-                          self.sq_partial.data_ptr(), self._stream()), 'c1v_grad_finalize')
+        def seg_table(keep):
+            """Descriptor table over the segments selected by `keep(name)` (block numbering restarts per table)."""
+            sel, nb = [], 0
+            for d, name in zip(segs, seg_names):
+                if keep(name):
+                    sel.append(L.SegDesc(d.slab, d.slab_stride, d.splits, d.reps, d.rep_stride, d.offset, d.count, d.frozen, nb))
+                    nb += (d.count + L.CHUNK - 1) // L.CHUNK
+            arr = (L.SegDesc * len(sel))(*sel)
+            return torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.dev), len(sel), nb
+
+        self.seg_descs, self.n_seg, self.fin_blocks = seg_table(lambda n: True)
+        self.sq_partial = torch.zeros(max(self.fin_blocks, 256), dtype=torch.float32, device=self.dev)
+        bucketed = self.world > 1 or self.force_bucketed
+        n_partial = 256 if bucketed else self.fin_blocks
+
+        def make_finalize(table, with_sq):
+            descs, n, blocks = table
+            self._keep.append(descs)
+
+            def fin():
+                L.check(f_fin(descs.data_ptr(), n, blocks, self.grads.data_ptr(),
+                              self.sq_partial.data_ptr() if with_sq else None, self._stream()), 'c1v_grad_finalize')
+            return fin
+
+        finalize = make_finalize((self.seg_descs, self.n_seg, self.fin_blocks), True)
+        # data-parallel buckets (reverse layer order, SURVEY 8d): the decoder-side gradients are complete after the
+        # first `n_dec_stages` backward stages and can be summed over the ranks while the rest of backward runs.  The
+        # flat buffer keeps the segments in layer order, so each bucket is one contiguous range of `grads`.
+        is_enc = lambda n: n.startswith('encoder_conv1d_') or n.startswith('z_heads')
+        self.ops_finalize_dec = [make_finalize(seg_table(lambda n: not is_enc(n)), False)]
+        self.ops_finalize_enc = [make_finalize(seg_table(is_enc), False)]
+        self.n_dec_stages = nd + 2
+        self.enc_range = (0, self.seg_off['deconv_decoder_dense/kernel'])
+        self.dec_range = (self.seg_off['deconv_decoder_dense/kernel'], self.P)
 
         def sqnorm():
             L.check(f_sq(self.grads.data_ptr(), self.P, self.sq_partial.data_ptr(), 256, self._stream()), 'c1v_sqnorm_partial')
@@ -568,7 +596,7 @@ class VAEEngine:
         self.ops_finalize = [finalize]
         nad = L.NadamArgs(self.params.data_ptr(), self.grads.data_ptr(), self.nadam_m.data_ptr(), self.nadam_v.data_ptr(),
                           self.P, 1.0, CLIPNORM, self.sched.data_ptr(), 0.9, 0.999, 1e-7, self.norm_out.data_ptr())
-        self.ops_update = ([] if self.world == 1 else [sqnorm]) + [advance, op('c1v_nadam_step', nad), self._pack_all]
+        self.ops_update = ([sqnorm] if bucketed else []) + [advance, op('c1v_nadam_step', nad), self._pack_all]
 
         # ---- RNG (device counter => replayable): eps + both dropout masks in ONE launch; the counter advances in
         # nadam_advance at the end of the step
@@ -613,6 +641,7 @@ class VAEEngine:
         if gr is None:
             torch.cuda.synchronize(self.dev)
             saved = self._save_state()
+            self._saved_for_capture = saved
             s = torch.cuda.Stream(self.dev)
             s.wait_stream(torch.cuda.current_stream(self.dev))
             with torch.cuda.stream(s):
@@ -621,7 +650,9 @@ class VAEEngine:
             torch.cuda.synchronize(self.dev)
             self._restore_state(saved)
             gr = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gr):
+            # thread_local: RCCL's watchdog thread may query events while this thread captures (only matters for graphs
+            # that contain collectives; harmless otherwise)
+            with torch.cuda.graph(gr, capture_error_mode='thread_local'):
                 self._run(ops)
             self._restore_state(saved)
             self._graphs[key] = gr
@@ -665,11 +696,12 @@ class VAEEngine:
         if ids is not None:
             self.ids_in.copy_(torch.as_tensor(ids, dtype=torch.int32), non_blocking=True)
 
-    def _run_backward(self):
-        """dgrad chain on the current stream, wgrads (and the loss scalars) on the side stream; joined at the end."""
+    def _run_backward(self, lo: int = 0, hi: Optional[int] = None):
+        """Stages [lo, hi) of backward: dgrad chain on the current stream, wgrads (and the loss scalars) on the side
+        stream; joined at the end."""
         main = torch.cuda.current_stream(self.dev)
         side = self.side_stream
-        for main_ops, side_ops in self.bwd_stages:
+        for main_ops, side_ops in self.bwd_stages[lo:hi]:
             if side_ops:
                 ev = torch.cuda.Event()
                 ev.record(main)
@@ -679,34 +711,78 @@ class VAEEngine:
             self._run(main_ops)
         main.wait_stream(side)
 
-    def train_ops(self, with_rng: bool, from_ids: bool = False):
-        fwd = (self.ops_rng if with_rng else []) + self._in_ops(from_ids) + self.ops_enc_train + self.ops_lat_train + \
+    def forward_ops(self, with_rng: bool, from_ids: bool = False):
+        return (self.ops_rng if with_rng else []) + self._in_ops(from_ids) + self.ops_enc_train + self.ops_lat_train + \
             self.ops_dec + self.ops_loss_train
-        return fwd + [self._run_backward] + self.ops_finalize
+
+    def train_ops(self, with_rng: bool, from_ids: bool = False):
+        return self.forward_ops(with_rng, from_ids) + [self._run_backward] + self.ops_finalize
 
     def train_step(self, use_graph: bool = True, fixed_rng: bool = False, all_reduce=None, from_ids: bool = False):
         """One fit step on the batch resident in x_in / ids_in: forward, loss, backward, clip, Nadam, operand refresh.
-        fixed_rng: eps / keep_e / keep_d were filled by the caller (parity runs)."""
+        fixed_rng: eps / keep_e / keep_d were filled by the caller (parity runs).
+
+        world > 1 (data parallel, one process per GPU): `all_reduce(t)` sums a slice of the flat fp32 gradient over the
+        ranks (RCCL over xGMI) and may return a work handle with `.wait()` (torch.distributed `async_op=True`).  The step
+        is three captured graphs around two bucketed collectives:
+            A1 = forward + loss + decoder-side backward + finalize(decoder bucket)   -> all-reduce(decoder bucket) starts
+            A2 = encoder-side backward + finalize(encoder bucket)                    -> runs WHILE bucket 1 is on the wire
+            B  = |g|^2 of the reduced gradient, clip, Nadam, operand refresh         -> after both buckets
+        Every loss term already carries 1/B_global, so the sum IS the full-batch gradient."""
         if self.N == 0:
             raise L.C1VError('train_step needs the vocabulary matrix (set_vocab)')
         sfx = '@ids' if from_ids else ''
-        if self.world == 1:
-            ops = self.train_ops(not fixed_rng, from_ids) + self.ops_update
+
+        def go(key, ops):
             if use_graph:
-                self._graph(('train_fixed' if fixed_rng else 'train') + sfx, ops)
+                self._graph(key + ('_fixed' if fixed_rng else '') + sfx, ops)
             else:
                 self._run(ops)
-        else:
-            a, b = self.train_ops(not fixed_rng, from_ids), self.ops_update
-            if use_graph:
-                self._graph(('train_a_fixed' if fixed_rng else 'train_a') + sfx, a)
-            else:
-                self._run(a)
-            all_reduce(self.grads)                      # RCCL sum over ranks; loss terms carry 1/B_global already
-            if use_graph:
-                self._graph('train_b', b)
-            else:
-                self._run(b)
+
+        if self.world == 1 and not self.force_bucketed:
+            go('train', self.train_ops(not fixed_rng, from_ids) + self.ops_update)
+            return
+        if all_reduce is None:
+            raise L.C1VError('world_size > 1 needs an all_reduce callable')
+        k = self.n_dec_stages
+        if use_graph and os.environ.get('C1V_DP_GRAPH', '1') == '1' and not getattr(self, '_dp_graph_failed', False):
+            # the two collectives are captured INTO the step's graph (RCCL supports hipGraph capture): one launch per
+            # step, bucket 1 on the wire while the encoder-side backward runs.  Rehearsed here with one rank only
+            # (`bench.py --force-dp-path`), so a capture failure falls back to the three-graph sequence below.
+            waits = []
+
+            def ar_dec():
+                waits.append(all_reduce(self.grads[self.dec_range[0]:self.dec_range[1]]))
+
+            def ar_enc():
+                waits.append(all_reduce(self.grads[self.enc_range[0]:self.enc_range[1]]))
+
+            def join():
+                for w in waits:
+                    if w is not None and hasattr(w, 'wait'):
+                        w.wait()
+                del waits[:]
+            try:
+                go('train_dp1', self.forward_ops(not fixed_rng, from_ids) + [lambda: self._run_backward(0, k)] +
+                   self.ops_finalize_dec + [ar_dec, lambda: self._run_backward(k, None)] + self.ops_finalize_enc +
+                   [ar_enc, join] + self.ops_update)
+                return
+            except Exception as exc:                                   # noqa: BLE001 - capture of a collective refused
+                import sys
+                print('c1dvae: capturing the RCCL collectives into the step graph failed (%s); using the three-graph '
+                      'sequence' % (exc,), file=sys.stderr)
+                self._dp_graph_failed = True
+                self._graphs.pop('train_dp1' + ('_fixed' if fixed_rng else '') + sfx, None)
+                if getattr(self, '_saved_for_capture', None) is not None:
+                    self._restore_state(self._saved_for_capture)
+        go('train_a1', self.forward_ops(not fixed_rng, from_ids) + [lambda: self._run_backward(0, k)] + self.ops_finalize_dec)
+        w1 = all_reduce(self.grads[self.dec_range[0]:self.dec_range[1]])
+        go('train_a2', [lambda: self._run_backward(k, None)] + self.ops_finalize_enc)
+        w2 = all_reduce(self.grads[self.enc_range[0]:self.enc_range[1]])
+        for w in (w1, w2):
+            if w is not None and hasattr(w, 'wait'):
+                w.wait()
+        go('train_b', self.ops_update)
 
     def eval_step(self, use_graph: bool = True, fixed_rng: bool = False, from_ids: bool = False):
         """Validation loss of the resident batch (dropout off, eps still sampled -- Keras test phase of FullVAE)."""

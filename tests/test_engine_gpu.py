@@ -229,3 +229,68 @@ def test_frozen_encoder_keeps_encoder_weights():
     gg = eng.get_grads()
     for k_, ref in grads.items():
         assert rel_err(gg[k_], ref) < 2e-4 or np.abs(ref).max() == 0 and np.abs(gg[k_]).max() == 0, k_
+
+
+def test_two_rank_bucketed_step_equals_single_rank_step():
+    """Data parallel by construction: two engines (rank 0 / 1 of world 2, half the batch each, on one GPU) stepped through
+    the bucketed sequence of `train_step` (A1 | all-reduce decoder bucket | A2 | all-reduce encoder bucket | B) end up
+    with the weights of ONE engine stepping the whole batch (fp32; the only difference is the summation order)."""
+    engine, geometry = _engine_mod()
+    c = dict(CASES['mid'])
+    og, params, Wv, x, ids, eps, mask_e, mask_d = make_case(c, seed=9)
+    V = c['E'] + 2
+    g = geometry.Geometry(c['T_in'], c['T_out'], V, V, c['n_filters'], c['k'], c['D'])
+    full = engine.VAEEngine(g, c['B'], Wv, dtype='f32', weights=params)
+    load_fixed(full, x, ids, eps, mask_e, mask_d)
+    h = c['B'] // 2
+    ranks = []
+    for r in range(2):
+        e = engine.VAEEngine(g, h, Wv, dtype='f32', weights=params, world_size=2, rank=r)
+        sl = slice(r * h, (r + 1) * h)
+        load_fixed(e, x[sl], ids[sl], eps[sl], mask_e[sl], mask_d[sl])
+        ranks.append(e)
+    assert ranks[0].dec_range[1] == ranks[0].P and ranks[0].enc_range[1] == ranks[0].dec_range[0]
+    for step in range(3):
+        full.train_step(use_graph=False, fixed_rng=True)
+        # the two "processes" interleaved at their collectives; the all-reduce is a sum of the two buckets
+        pending = []
+
+        def make_ar(r):
+            def ar(t):
+                pending.append((r, t))
+            return ar
+        k = ranks[0].n_dec_stages
+        for e in ranks:
+            e._run(e.forward_ops(False) + [lambda e=e: e._run_backward(0, k)] + e.ops_finalize_dec)
+        lo, hi = ranks[0].dec_range
+        tot = ranks[0].grads[lo:hi] + ranks[1].grads[lo:hi]
+        for e in ranks:
+            e.grads[lo:hi].copy_(tot)
+        for e in ranks:
+            e._run([lambda e=e: e._run_backward(k, None)] + e.ops_finalize_enc)
+        lo, hi = ranks[0].enc_range
+        tot = ranks[0].grads[lo:hi] + ranks[1].grads[lo:hi]
+        for e in ranks:
+            e.grads[lo:hi].copy_(tot)
+        for e in ranks:
+            e._run(e.ops_update)
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(ranks[0].grads.cpu().numpy(), full.grads.cpu().numpy(), rtol=2e-4, atol=1e-7)
+    w_full, w0, w1 = full.get_weights(), ranks[0].get_weights(), ranks[1].get_weights()
+    for k_ in w_full:
+        assert np.array_equal(w0[k_], w1[k_]), k_                       # replicas stay bit-identical
+        upd = w_full[k_].astype(np.float64) - params[k_]
+        assert rel_err(w0[k_].astype(np.float64) - params[k_], upd) < 5e-3, k_
+    # and the public entry point runs the same sequence (world 2 emulated with an identity "all-reduce" x2)
+    e = engine.VAEEngine(g, h, Wv, dtype='bf16', weights=params, world_size=2, rank=0)
+    load_fixed(e, x[:h], ids[:h], eps[:h], mask_e[:h], mask_d[:h])
+    calls = []
+
+    def fake_all_reduce(t):
+        calls.append(t.numel())
+        t.mul_(2.0)
+
+    for _ in range(2):
+        e.train_step(use_graph=True, fixed_rng=True, all_reduce=fake_all_reduce)
+    torch.cuda.synchronize()
+    assert calls[:2] == [e.dec_range[1] - e.dec_range[0], e.enc_range[1] - e.enc_range[0]] and np.isfinite(e.loss())
