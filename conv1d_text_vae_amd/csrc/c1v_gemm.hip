@@ -64,111 +64,146 @@ __device__ __forceinline__ void store4(const EpiDev& e, int64_t idx, const float
     for (int k = 0; k < count; ++k) store_any(e.dst, e.dst_dtype, idx + k, v[k]);
 }
 
-template <int BM, int BN>
-__device__ __forceinline__ void epilogue_tile(const EpiDev& e, const float* ct, int LDC, int m0, int n0, int tid) {
-    constexpr int G = BN / 4;                                  // 4-channel groups per tile row
-    const bool pairs = (e.row_mode == C1V_ROW_POOL2) || (e.row_mode == C1V_ROW_PAIRSUM);
-    const int items = (pairs ? BM / 2 : BM) * G;
+// A thread owns ONE 4-channel group (g = tid % G) of every (256/G)-th tile row, so its bias values are loaded once -- by
+// the kernel, before the K loop, where the latency is free -- and its rows are processed in chunks of up to four: first
+// the mask / dropout / pool bytes of the whole chunk are requested, then values are formed and stored (a rolled
+// one-row-per-iteration loop serialised one global-load latency per row, ~1.5 us each).
+template <int BM, int BN, int MODE>
+__device__ __forceinline__ void epilogue_rows(const EpiDev& e, const float* ct, int LDC, int m0, int n0, int tid, const float bias4[4]) {
+    constexpr bool PAIRS = MODE == C1V_ROW_POOL2 || MODE == C1V_ROW_PAIRSUM;
+    constexpr int G = BN / 4, RPI = 256 / G, ROWS = PAIRS ? BM / 2 : BM, ITEMS = ROWS / RPI, CH = ITEMS < 4 ? ITEMS : 4;
+    static_assert(256 % G == 0 && ROWS % RPI == 0 && ITEMS % CH == 0, "tile shape");
+    const int g = tid % G, r0 = tid / G;
+    const int n = n0 + 4 * g;
+    if (n >= e.N) return;
+    const int cnt = e.N - n < 4 ? e.N - n : 4;                      // valid channels of this group
+    int tn = 0, c = n;
+    if (e.reshape_w > 0) { tn = n / e.reshape_w; c = n - tn * e.reshape_w; }
+    const bool straddle = e.reshape_w > 0 && c + cnt > e.reshape_w;  // group crosses a (t, c) row boundary: element-wise
+    constexpr int mode = MODE;                        // compile-time: every mode test below folds away
 #pragma unroll 1
-    for (int it = tid; it < items; it += 256) {
-        const int rr = it / G, g = it - rr * G;
-        const int row = pairs ? 2 * rr : rr;
-        const int m = m0 + row, n = n0 + 4 * g;
-        if (m >= e.M || n >= e.N) continue;
-        const int b = m / e.Le, u = m - b * e.Le;
-        const int cnt = e.N - n < 4 ? e.N - n : 4;             // valid channels of this group
-        const float4 c0 = *(const float4*)(ct + row * LDC + 4 * g);
-        float v[4] = {c0.x, c0.y, c0.z, c0.w};
-        float w[4] = {0.f, 0.f, 0.f, 0.f};
-        if (pairs) { const float4 c1 = *(const float4*)(ct + (row + 1) * LDC + 4 * g); w[0] = c1.x; w[1] = c1.y; w[2] = c1.z; w[3] = c1.w; }
+    for (int j0 = 0; j0 < ITEMS; j0 += CH) {
+        bool ok[CH];
+        int bb[CH], uu[CH], tt[CH];
+        float am[CH][4];
+        uint8_t by[CH][4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const float bv = (e.bias && k < cnt) ? e.bias[n + k] : 0.0f;
-            v[k] += bv; w[k] += bv;
-            if (e.relu) { v[k] = fmaxf(v[k], 0.0f); w[k] = fmaxf(w[k], 0.0f); }
-            if (e.exp2) v[k] = exp2f(v[k]);
-        }
-        if (e.reshape_w > 0) {
-            // column split (t, c) = divmod(n, reshape_w): element-wise (only the two small dense layers use it)
-            if (u >= e.nrows) continue;
-            for (int k = 0; k < cnt; ++k) {
-                const int t = (n + k) / e.reshape_w, c = (n + k) - t * e.reshape_w;
-                float x = v[k];
-                if (e.row_mode == C1V_ROW_STORE) {
-                    if (t >= e.dst_len) continue;
-                    if (e.act) x *= load_any(e.act, e.act_dtype, (int64_t)b * e.act_bstride + (int64_t)(e.act_off + t * e.act_rowmul) * e.act_cp + c) > 0.0f ? e.act_scale : 0.0f;
-                    if (e.keep) x = e.keep[(int64_t)b * e.sel_bstride + (int64_t)t * e.sel_cp + c] ? x * e.keep_scale : 0.0f;
-                    store_any(e.dst, e.dst_dtype, (int64_t)b * e.dst_bstride + (int64_t)(e.dst_off + t) * e.dst_cp + c, x);
-                } else {   // UNPOOL
-                    if (2 * t + 1 >= e.dst_len) continue;
-                    if (e.act) x *= load_any(e.act, e.act_dtype, (int64_t)b * e.act_bstride + (int64_t)(e.act_off + t * e.act_rowmul) * e.act_cp + c) > 0.0f ? e.act_scale : 0.0f;
-                    const int sidx = e.sel[(int64_t)b * e.sel_bstride + (int64_t)t * e.sel_cp + c] ? 1 : 0;
-                    const int64_t d = (int64_t)b * e.dst_bstride + (int64_t)(e.dst_off + 2 * t) * e.dst_cp + c;
-                    store_any(e.dst, e.dst_dtype, d + (int64_t)sidx * e.dst_cp, x);
-                    store_any(e.dst, e.dst_dtype, d + (int64_t)(1 - sidx) * e.dst_cp, 0.0f);
+        for (int jj = 0; jj < CH; ++jj) {
+            const int rr = r0 + (j0 + jj) * RPI;
+            const int m = m0 + (PAIRS ? 2 * rr : rr);
+            const int mm = m < e.M ? m : e.M - 1;
+            const int b = mm / e.Le, u = mm - b * e.Le;
+            const int t = e.reshape_w > 0 ? tn : (PAIRS ? (u >> 1) : u);
+            bool o = m < e.M;
+            if (mode == C1V_ROW_STORE) o = o && u < e.nrows && t < e.dst_len;
+            else if (mode == C1V_ROW_UP2) o = o && u < e.nrows && 2 * t < e.dst_len;
+            else if (mode == C1V_ROW_UNPOOL) o = o && u < e.nrows && 2 * t + 1 < e.dst_len;
+            else if (mode == C1V_ROW_POOL2) o = o && t < e.dst_len && u + 1 < e.nrows;
+            else o = o && t < e.dst_len;
+            ok[jj] = o; bb[jj] = b; uu[jj] = u; tt[jj] = t;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { am[jj][k] = 1.0f; by[jj][k] = 1; }
+            if (o && !straddle) {
+                if (e.act && mode != C1V_ROW_UP2 && mode != C1V_ROW_POOL2) {
+                    const int64_t ai = (int64_t)b * e.act_bstride + (int64_t)(e.act_off + t * e.act_rowmul) * e.act_cp + c;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) if (k < cnt) am[jj][k] = load_any(e.act, e.act_dtype, ai + k);
+                }
+                const int64_t si = (int64_t)b * e.sel_bstride + (int64_t)t * e.sel_cp + c;
+                if (mode == C1V_ROW_UNPOOL) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) if (k < cnt) by[jj][k] = e.sel[si + k];
+                } else if (e.keep && (mode == C1V_ROW_STORE || mode == C1V_ROW_POOL2)) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) if (k < cnt) by[jj][k] = e.keep[si + k];
                 }
             }
-            continue;
         }
-        // from here on (t, c) = (u or u/2, n .. n+3): the four channels are contiguous in every buffer involved
-        const int t = pairs ? (u >> 1) : u;
-        const int64_t si = (int64_t)b * e.sel_bstride + (int64_t)t * e.sel_cp + n;
-        float am[4] = {1.f, 1.f, 1.f, 1.f};
-        if (e.act && e.row_mode != C1V_ROW_UP2 && e.row_mode != C1V_ROW_POOL2) {
-            const int64_t ai = (int64_t)b * e.act_bstride + (int64_t)(e.act_off + t * e.act_rowmul) * e.act_cp + n;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) if (k < cnt) am[k] = load_any(e.act, e.act_dtype, ai + k) > 0.0f ? e.act_scale : 0.0f;
-        }
-        if (e.row_mode == C1V_ROW_STORE) {
-            if (u >= e.nrows || t >= e.dst_len) continue;
+        for (int jj = 0; jj < CH; ++jj) {
+            if (!ok[jj]) continue;
+            const int rr = r0 + (j0 + jj) * RPI;
+            const int row = PAIRS ? 2 * rr : rr;
+            const int b = bb[jj], u = uu[jj], t = tt[jj];
+            const float4 q0 = *(const float4*)(ct + row * LDC + 4 * g);
+            float v[4] = {q0.x, q0.y, q0.z, q0.w};
+            float w[4] = {0.f, 0.f, 0.f, 0.f};
+            if (PAIRS) { const float4 q1 = *(const float4*)(ct + (row + 1) * LDC + 4 * g); w[0] = q1.x; w[1] = q1.y; w[2] = q1.z; w[3] = q1.w; }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                v[k] *= am[k];
-                if (e.keep && k < cnt) v[k] = e.keep[si + k] ? v[k] * e.keep_scale : 0.0f;
+                v[k] += bias4[k]; w[k] += bias4[k];
+                if (e.relu) { v[k] = fmaxf(v[k], 0.0f); w[k] = fmaxf(w[k], 0.0f); }
+                if (e.exp2) v[k] = exp2f(v[k]);
+                am[jj][k] = (e.act && mode != C1V_ROW_UP2 && mode != C1V_ROW_POOL2) ? (am[jj][k] > 0.0f ? e.act_scale : 0.0f) : 1.0f;
             }
-            store4(e, (int64_t)b * e.dst_bstride + (int64_t)(e.dst_off + t) * e.dst_cp + n, v, cnt);
-        } else if (e.row_mode == C1V_ROW_UP2) {
-            if (u >= e.nrows || 2 * t >= e.dst_len) continue;
-            const int64_t d = (int64_t)b * e.dst_bstride + (int64_t)(e.dst_off + 2 * t) * e.dst_cp + n;
-            store4(e, d, v, cnt);
-            if (2 * t + 1 < e.dst_len) store4(e, d + e.dst_cp, v, cnt);
-        } else if (e.row_mode == C1V_ROW_UNPOOL) {
-            if (u >= e.nrows || 2 * t + 1 >= e.dst_len) continue;
-            float hi[4], lo[4];                                  // row 2t and row 2t+1
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const bool s1 = k < cnt ? (e.sel[si + k] != 0) : false;
-                const float x = v[k] * am[k];
-                hi[k] = s1 ? 0.0f : x; lo[k] = s1 ? x : 0.0f;
-            }
-            const int64_t d = (int64_t)b * e.dst_bstride + (int64_t)(e.dst_off + 2 * t) * e.dst_cp + n;
-            store4(e, d, hi, cnt);
-            store4(e, d + e.dst_cp, lo, cnt);
-        } else if (e.row_mode == C1V_ROW_POOL2) {
-            if (t >= e.dst_len || u + 1 >= e.nrows) continue;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const bool s1 = w[k] > v[k];                    // first maximum wins ties
-                float x = s1 ? w[k] : v[k];
-                if (k < cnt) {
-                    if (e.sel) e.sel[si + k] = s1 ? 1 : 0;
-                    if (e.keep) x = e.keep[si + k] ? x * e.keep_scale : 0.0f;
+            if (straddle) {
+                // element-wise (t, c) = divmod(n + k, reshape_w); only dense layers whose width is not a multiple of 4
+                for (int k = 0; k < cnt; ++k) {
+                    const int te = (n + k) / e.reshape_w, ce = (n + k) - te * e.reshape_w;
+                    float x = v[k];
+                    if (mode == C1V_ROW_STORE) {
+                        if (te >= e.dst_len) continue;
+                        if (e.act) x *= load_any(e.act, e.act_dtype, (int64_t)b * e.act_bstride + (int64_t)(e.act_off + te * e.act_rowmul) * e.act_cp + ce) > 0.0f ? e.act_scale : 0.0f;
+                        if (e.keep) x = e.keep[(int64_t)b * e.sel_bstride + (int64_t)te * e.sel_cp + ce] ? x * e.keep_scale : 0.0f;
+                        store_any(e.dst, e.dst_dtype, (int64_t)b * e.dst_bstride + (int64_t)(e.dst_off + te) * e.dst_cp + ce, x);
+                    } else {   // UNPOOL
+                        if (2 * te + 1 >= e.dst_len) continue;
+                        if (e.act) x *= load_any(e.act, e.act_dtype, (int64_t)b * e.act_bstride + (int64_t)(e.act_off + te * e.act_rowmul) * e.act_cp + ce) > 0.0f ? e.act_scale : 0.0f;
+                        const int sidx = e.sel[(int64_t)b * e.sel_bstride + (int64_t)te * e.sel_cp + ce] ? 1 : 0;
+                        const int64_t d = (int64_t)b * e.dst_bstride + (int64_t)(e.dst_off + 2 * te) * e.dst_cp + ce;
+                        store_any(e.dst, e.dst_dtype, d + (int64_t)sidx * e.dst_cp, x);
+                        store_any(e.dst, e.dst_dtype, d + (int64_t)(1 - sidx) * e.dst_cp, 0.0f);
+                    }
                 }
-                v[k] = x;
+                continue;
             }
-            store4(e, (int64_t)b * e.dst_bstride + (int64_t)(e.dst_off + t) * e.dst_cp + n, v, cnt);
-        } else {   // PAIRSUM
-            if (t >= e.dst_len) continue;
+            const int64_t si = (int64_t)b * e.sel_bstride + (int64_t)t * e.sel_cp + c;
+            if (mode == C1V_ROW_STORE) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = ((u < e.nrows ? v[k] : 0.0f) + (u + 1 < e.nrows ? w[k] : 0.0f)) * am[k];
-            store4(e, (int64_t)b * e.dst_bstride + (int64_t)(e.dst_off + t) * e.dst_cp + n, v, cnt);
+                for (int k = 0; k < 4; ++k) {
+                    v[k] *= am[jj][k];
+                    if (e.keep) v[k] = by[jj][k] ? v[k] * e.keep_scale : 0.0f;
+                }
+                store4(e, (int64_t)b * e.dst_bstride + (int64_t)(e.dst_off + t) * e.dst_cp + c, v, cnt);
+            } else if (mode == C1V_ROW_UP2) {
+                const int64_t d = (int64_t)b * e.dst_bstride + (int64_t)(e.dst_off + 2 * t) * e.dst_cp + c;
+                store4(e, d, v, cnt);
+                if (2 * t + 1 < e.dst_len) store4(e, d + e.dst_cp, v, cnt);
+            } else if (mode == C1V_ROW_UNPOOL) {
+                float hi[4], lo[4];                                  // row 2t and row 2t+1
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const bool s1 = k < cnt && by[jj][k] != 0;
+                    const float x = v[k] * am[jj][k];
+                    hi[k] = s1 ? 0.0f : x; lo[k] = s1 ? x : 0.0f;
+                }
+                const int64_t d = (int64_t)b * e.dst_bstride + (int64_t)(e.dst_off + 2 * t) * e.dst_cp + c;
+                store4(e, d, hi, cnt);
+                store4(e, d + e.dst_cp, lo, cnt);
+            } else if (mode == C1V_ROW_POOL2) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const bool s1 = w[k] > v[k];                    // first maximum wins ties
+                    float x = s1 ? w[k] : v[k];
+                    if (k < cnt) {
+                        if (e.sel) e.sel[si + k] = s1 ? 1 : 0;
+                        if (e.keep) x = by[jj][k] ? x * e.keep_scale : 0.0f;
+                    }
+                    v[k] = x;
+                }
+                store4(e, (int64_t)b * e.dst_bstride + (int64_t)(e.dst_off + t) * e.dst_cp + c, v, cnt);
+            } else {   // PAIRSUM
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = ((u < e.nrows ? v[k] : 0.0f) + (u + 1 < e.nrows ? w[k] : 0.0f)) * am[jj][k];
+                store4(e, (int64_t)b * e.dst_bstride + (int64_t)(e.dst_off + t) * e.dst_cp + c, v, cnt);
+            }
         }
     }
 }
 
 #ifdef NT_STAMP
 // diagnostic build only: cycle stamps of wave 0 of every workgroup (start, after prologue, after K loop, end)
-__device__ unsigned long long nt_dbg[4 * 8192];
+__device__ unsigned long long nt_dbg[8 * 8192];
 extern "C" int c1v_debug_read_nt(unsigned long long* dst, int n) {
     return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(nt_dbg), sizeof(unsigned long long) * n);
 }
@@ -181,7 +216,7 @@ extern "C" int c1v_debug_read_nt(unsigned long long* dst, int n) {
 template <typename T, int BM, int BN, int NS>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(const NtParams p) {
 #ifdef NT_STAMP
-    unsigned long long stamp[4];
+    unsigned long long stamp[8];
 #endif
     NT_T(0);
     constexpr int WTM = BM / 2, WTN = BN / 2, MI = WTM / 16, NJ = WTN / 16;
@@ -235,6 +270,13 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const NtParams p) {
 #pragma unroll
     for (int s = 0; s < NS - 1; ++s)
         if (s < KT) issue(s);
+    // bias of this thread's epilogue channel group (see epilogue_rows): requested now, consumed after the K loop
+    float bias4[4];
+    {
+        const int nbias = n0 + 4 * (tid % (BN / 4));
+#pragma unroll
+        for (int k = 0; k < 4; ++k) bias4[k] = (p.e.bias && nbias + k < p.e.N) ? p.e.bias[nbias + k] : 0.0f;
+    }
     NT_T(1);
 
     for (int kt = 0; kt < KT; ++kt) {
@@ -269,6 +311,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const NtParams p) {
     constexpr int LDC = BN + 4;
     float* ct = (float*)smem;
     __syncthreads();                                   // every wave is done reading the last operand stage
+    NT_T(4);
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -277,12 +320,31 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const NtParams p) {
             for (int r = 0; r < 4; ++r)
                 ct[(wm * WTM + i * 16 + (lane >> 4) * 4 + r) * LDC + wn * WTN + j * 16 + (lane & 15)] = acc[i][j][r];
     __syncthreads();
-    epilogue_tile<BM, BN>(p.e, ct, LDC, m0, n0, tid);
+    NT_T(5);
+    switch (p.e.row_mode) {                            // wave-uniform; one specialised epilogue each
+        case C1V_ROW_STORE:   epilogue_rows<BM, BN, C1V_ROW_STORE>(p.e, ct, LDC, m0, n0, tid, bias4); break;
+        case C1V_ROW_POOL2:   epilogue_rows<BM, BN, C1V_ROW_POOL2>(p.e, ct, LDC, m0, n0, tid, bias4); break;
+        case C1V_ROW_UP2:     epilogue_rows<BM, BN, C1V_ROW_UP2>(p.e, ct, LDC, m0, n0, tid, bias4); break;
+        case C1V_ROW_PAIRSUM: epilogue_rows<BM, BN, C1V_ROW_PAIRSUM>(p.e, ct, LDC, m0, n0, tid, bias4); break;
+        default:              epilogue_rows<BM, BN, C1V_ROW_UNPOOL>(p.e, ct, LDC, m0, n0, tid, bias4); break;
+    }
 #ifdef NT_STAMP
+    NT_T(6);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     NT_T(3);
+#ifdef NT_TWICE
+    // diagnostic: the same epilogue a second time (same values stored again) -- hot instruction cache, hot data
+    switch (p.e.row_mode) {                            // wave-uniform; one specialised epilogue each
+        case C1V_ROW_STORE:   epilogue_rows<BM, BN, C1V_ROW_STORE>(p.e, ct, LDC, m0, n0, tid, bias4); break;
+        case C1V_ROW_POOL2:   epilogue_rows<BM, BN, C1V_ROW_POOL2>(p.e, ct, LDC, m0, n0, tid, bias4); break;
+        case C1V_ROW_UP2:     epilogue_rows<BM, BN, C1V_ROW_UP2>(p.e, ct, LDC, m0, n0, tid, bias4); break;
+        case C1V_ROW_PAIRSUM: epilogue_rows<BM, BN, C1V_ROW_PAIRSUM>(p.e, ct, LDC, m0, n0, tid, bias4); break;
+        default:              epilogue_rows<BM, BN, C1V_ROW_UNPOOL>(p.e, ct, LDC, m0, n0, tid, bias4); break;
+    }
+    NT_T(7);
+#endif
     const int wg = blockIdx.x + gridDim.x * blockIdx.y;
-    if (tid == 0 && wg < 8192) for (int i = 0; i < 4; ++i) nt_dbg[wg * 4 + i] = stamp[i];
+    if (tid == 0 && wg < 8192) for (int i = 0; i < 8; ++i) nt_dbg[wg * 8 + i] = stamp[i];
 #endif
 }
 
