@@ -201,9 +201,230 @@ __device__ __forceinline__ void epilogue_rows(const EpiDev& e, const float* ct, 
     }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// vectorised epilogue (EpiDev::fastw = 4 or 2, decided on the host by c1v_fill_epi): every address a 4-channel group
+// touches is a multiple of VW elements, so activations / mask bytes / results move as whole 4-, 8- or 16-byte words and
+// nothing is branched per element.  The inputs of the first chunk of rows are requested BEFORE the K loop (their
+// latency hides behind it); the row -> (sample, step) split uses one scalar division per workgroup (RowDiv).
+// ------------------------------------------------------------------------------------------------------
+struct RowDiv { int Le, b0, u0; float rcp; };
+__device__ __forceinline__ RowDiv make_rowdiv(int m0, int Le) {
+    RowDiv d;
+    d.Le = Le; d.b0 = m0 / Le; d.u0 = m0 - d.b0 * Le; d.rcp = 1.0f / (float)Le;
+    return d;
+}
+// (b, u) of row m0 + r, 0 <= r < 2^15: float estimate of the quotient, exact after one correction step
+__device__ __forceinline__ void rowdiv(const RowDiv& d, int r, int& b, int& u) {
+    const int x = d.u0 + r;
+    int q = (int)((float)x * d.rcp);
+    int rem = x - q * d.Le;
+    if (rem < 0) { --q; rem += d.Le; } else if (rem >= d.Le) { ++q; rem -= d.Le; }
+    b = d.b0 + q; u = rem;
+}
+
+struct EpiState {
+    static constexpr int CH = 4;
+    int64_t di[CH];        // destination element index of the group (row 2t for UP2 / UNPOOL)
+    int si[CH];            // index of the group's mask bytes (sel / keep)
+    uint4 act[CH];         // raw activation words: bf16 in .x .y, fp32 in .x .. .w
+    uint32_t by[CH];       // four mask bytes
+    uint32_t flags;        // 4 bits per row: 1 = stored, 2 = UP2: second row fits / PAIRSUM: first member valid, 4 = PAIRSUM: second member valid
+    int cnt;               // valid channels of the group (VW = 4: always 4; VW = 2: 2 or 4); 0 = thread idle
+};
+
+template <int VW> __device__ __forceinline__ uint4 epi_ld_act(const EpiDev& e, int64_t i, int cnt) {
+    uint4 r = make_uint4(0u, 0u, 0u, 0u);
+    if (e.act_dtype == C1V_F32) {
+        const float* p = (const float*)e.act + i;
+        if (VW == 4) r = *(const uint4*)p;
+        else { const uint2 a = *(const uint2*)p; r.x = a.x; r.y = a.y; if (cnt == 4) { const uint2 b = *(const uint2*)(p + 2); r.z = b.x; r.w = b.y; } }
+    } else {
+        const bf16_raw* p = (const bf16_raw*)e.act + i;
+        if (VW == 4) { const uint2 a = *(const uint2*)p; r.x = a.x; r.y = a.y; }
+        else { r.x = *(const uint32_t*)p; if (cnt == 4) r.y = *(const uint32_t*)(p + 2); }
+    }
+    return r;
+}
+template <int VW> __device__ __forceinline__ uint32_t epi_ld_bytes(const uint8_t* p, int cnt) {
+    if (VW == 4) return *(const uint32_t*)p;
+    uint32_t r = *(const uint16_t*)p;
+    r |= (cnt == 4 ? (uint32_t)*(const uint16_t*)(p + 2) : 0x0101u) << 16;
+    return r;
+}
+template <int VW> __device__ __forceinline__ void epi_st_bytes(uint8_t* p, uint32_t v, int cnt) {
+    if (VW == 4) { *(uint32_t*)p = v; return; }
+    *(uint16_t*)p = (uint16_t)v;
+    if (cnt == 4) *(uint16_t*)(p + 2) = (uint16_t)(v >> 16);
+}
+template <int VW> __device__ __forceinline__ void epi_st(const EpiDev& e, int64_t i, const float v[4], int cnt) {
+    if (e.dst_dtype == C1V_F32) {
+        float* d = (float*)e.dst + i;
+        if (VW == 4) *(float4*)d = make_float4(v[0], v[1], v[2], v[3]);
+        else { *(float2*)d = make_float2(v[0], v[1]); if (cnt == 4) *(float2*)(d + 2) = make_float2(v[2], v[3]); }
+    } else {
+        bf16_raw* d = (bf16_raw*)e.dst + i;
+        if (VW == 4) *(uint2*)d = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+        else { *(uint32_t*)d = pack_bf16x2(v[0], v[1]); if (cnt == 4) *(uint32_t*)(d + 2) = pack_bf16x2(v[2], v[3]); }
+    }
+}
+
+template <int BM, int BN, int MODE> struct EpiShape {
+    static constexpr bool PAIRS = MODE == C1V_ROW_POOL2 || MODE == C1V_ROW_PAIRSUM;
+    static constexpr int G = BN / 4, RPI = 256 / G, ROWS = PAIRS ? BM / 2 : BM, ITEMS = ROWS / RPI, CH = ITEMS < 4 ? ITEMS : 4;
+    static_assert(256 % G == 0 && ROWS % RPI == 0 && ITEMS % CH == 0 && (ITEMS == CH || ITEMS % (2 * CH) == 0), "tile shape");
+};
+
+template <int BM, int BN, int MODE, int VW>
+__device__ __forceinline__ void epi_load(const EpiDev& e, const RowDiv& rd, EpiState& st, int m0, int n0, int tid, int j0) {
+    using S = EpiShape<BM, BN, MODE>;
+    constexpr bool PAIRS = S::PAIRS;
+    constexpr int G = S::G, RPI = S::RPI, CH = S::CH;
+    constexpr bool USE_ACT = MODE != C1V_ROW_UP2 && MODE != C1V_ROW_POOL2;
+    const int g = tid % G, r0 = tid / G;
+    const int n = n0 + 4 * g;
+    st.flags = 0; st.cnt = 0;
+    if (n >= e.N) return;
+    const int cnt = (VW == 4 || e.N - n >= 4) ? 4 : 2;
+    st.cnt = cnt;
+    int tn = 0, c = n;
+    if (e.reshape_w > 0) { tn = n / e.reshape_w; c = n - tn * e.reshape_w; }
+#pragma unroll
+    for (int jj = 0; jj < CH; ++jj) {
+        const int rr = r0 + (j0 + jj) * RPI;
+        const int r = PAIRS ? 2 * rr : rr;
+        int b, u;
+        rowdiv(rd, r, b, u);
+        const int t = e.reshape_w > 0 ? tn : (PAIRS ? (u >> 1) : u);
+        bool o = m0 + r < e.M;
+        uint32_t f = 0;
+        if (MODE == C1V_ROW_STORE) o = o && u < e.nrows && t < e.dst_len;
+        else if (MODE == C1V_ROW_UP2) { o = o && u < e.nrows && 2 * t < e.dst_len; f = 2 * t + 1 < e.dst_len ? 2u : 0u; }
+        else if (MODE == C1V_ROW_UNPOOL) o = o && u < e.nrows && 2 * t + 1 < e.dst_len;
+        else if (MODE == C1V_ROW_POOL2) o = o && t < e.dst_len && u + 1 < e.nrows;
+        else { o = o && t < e.dst_len; f = (u < e.nrows ? 2u : 0u) | (u + 1 < e.nrows ? 4u : 0u); }
+        const int trow = (MODE == C1V_ROW_UP2 || MODE == C1V_ROW_UNPOOL) ? 2 * t : t;
+        st.di[jj] = (int64_t)b * e.dst_bstride + (int64_t)(e.dst_off + trow) * e.dst_cp + c;
+        st.si[jj] = (int)((int64_t)b * e.sel_bstride + (int64_t)t * e.sel_cp + c);
+        st.act[jj] = make_uint4(0u, 0u, 0u, 0u);
+        st.by[jj] = 0x01010101u;
+        if (o) {
+            st.flags |= (1u | f) << (4 * jj);
+            if (USE_ACT && e.act)
+                st.act[jj] = epi_ld_act<VW>(e, (int64_t)b * e.act_bstride + (int64_t)(e.act_off + t * e.act_rowmul) * e.act_cp + c, cnt);
+            if (MODE == C1V_ROW_UNPOOL) st.by[jj] = epi_ld_bytes<VW>(e.sel + st.si[jj], cnt);
+            else if (e.keep && (MODE == C1V_ROW_STORE || MODE == C1V_ROW_POOL2)) st.by[jj] = epi_ld_bytes<VW>(e.keep + st.si[jj], cnt);
+        }
+    }
+}
+
+template <int BM, int BN, int MODE, int VW>
+__device__ __forceinline__ void epi_finish(const EpiDev& e, const EpiState& st, const float* ct, int LDC, int tid, int j0, const float bias4[4]) {
+    using S = EpiShape<BM, BN, MODE>;
+    constexpr bool PAIRS = S::PAIRS;
+    constexpr int G = S::G, RPI = S::RPI, CH = S::CH;
+    constexpr bool USE_ACT = MODE != C1V_ROW_UP2 && MODE != C1V_ROW_POOL2;
+    if (st.flags == 0) return;
+    const int g = tid % G, r0 = tid / G;
+    const int cnt = st.cnt;
+    const bool have_act = USE_ACT && e.act != nullptr;
+#pragma unroll
+    for (int jj = 0; jj < CH; ++jj) {
+        const uint32_t f = (st.flags >> (4 * jj)) & 15u;
+        if (!(f & 1u)) continue;
+        const int rr = r0 + (j0 + jj) * RPI;
+        const int row = PAIRS ? 2 * rr : rr;
+        const float4 q0 = *(const float4*)(ct + row * LDC + 4 * g);
+        float v[4] = {q0.x, q0.y, q0.z, q0.w};
+        float w[4] = {0.f, 0.f, 0.f, 0.f};
+        if (PAIRS) { const float4 q1 = *(const float4*)(ct + (row + 1) * LDC + 4 * g); w[0] = q1.x; w[1] = q1.y; w[2] = q1.z; w[3] = q1.w; }
+        float am[4];
+        const uint32_t aw[4] = {st.act[jj].x, st.act[jj].y, st.act[jj].z, st.act[jj].w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            v[k] += bias4[k]; w[k] += bias4[k];
+            if (e.relu) { v[k] = fmaxf(v[k], 0.0f); w[k] = fmaxf(w[k], 0.0f); }
+            if (e.exp2) v[k] = exp2f(v[k]);
+            float a = 1.0f;
+            if (have_act) {
+                const float x = e.act_dtype == C1V_F32 ? __uint_as_float(aw[k]) : __uint_as_float((k & 1) ? (aw[k >> 1] & 0xFFFF0000u) : (aw[k >> 1] << 16));
+                a = x > 0.0f ? e.act_scale : 0.0f;
+            }
+            am[k] = a;
+        }
+        const uint32_t by = st.by[jj];
+        const int64_t d = st.di[jj];
+        if (MODE == C1V_ROW_STORE) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                v[k] *= am[k];
+                if (e.keep) v[k] = ((by >> (8 * k)) & 255u) ? v[k] * e.keep_scale : 0.0f;
+            }
+            epi_st<VW>(e, d, v, cnt);
+        } else if (MODE == C1V_ROW_UP2) {
+            epi_st<VW>(e, d, v, cnt);
+            if (f & 2u) epi_st<VW>(e, d + e.dst_cp, v, cnt);
+        } else if (MODE == C1V_ROW_UNPOOL) {
+            float hi[4], lo[4];                                  // row 2t and row 2t+1
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const bool s1 = ((by >> (8 * k)) & 255u) != 0;
+                const float x = v[k] * am[k];
+                hi[k] = s1 ? 0.0f : x; lo[k] = s1 ? x : 0.0f;
+            }
+            epi_st<VW>(e, d, hi, cnt);
+            epi_st<VW>(e, d + e.dst_cp, lo, cnt);
+        } else if (MODE == C1V_ROW_POOL2) {
+            uint32_t sb = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const bool s1 = w[k] > v[k];                    // first maximum wins ties
+                float x = s1 ? w[k] : v[k];
+                sb |= (s1 ? 1u : 0u) << (8 * k);
+                if (e.keep) x = ((by >> (8 * k)) & 255u) ? x * e.keep_scale : 0.0f;
+                v[k] = x;
+            }
+            if (e.sel) epi_st_bytes<VW>(e.sel + st.si[jj], sb, cnt);
+            epi_st<VW>(e, d, v, cnt);
+        } else {   // PAIRSUM
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = (((f & 2u) ? v[k] : 0.0f) + ((f & 4u) ? w[k] : 0.0f)) * am[k];
+            epi_st<VW>(e, d, v, cnt);
+        }
+    }
+}
+
+// all rows of the tile: chunk 0 was requested before the K loop (s0); further chunks (128-row tiles) ping-pong
+template <int BM, int BN, int MODE, int VW>
+__device__ __forceinline__ void epi_fast_rows(const EpiDev& e, const RowDiv& rd, EpiState& s0, const float* ct, int LDC, int m0, int n0, int tid,
+                                              const float bias4[4]) {
+    using S = EpiShape<BM, BN, MODE>;
+    if constexpr (S::ITEMS == S::CH) {
+        epi_finish<BM, BN, MODE, VW>(e, s0, ct, LDC, tid, 0, bias4);
+    } else {
+        EpiState s1;
+#pragma unroll 1
+        for (int j0 = 0; j0 < S::ITEMS; j0 += 2 * S::CH) {
+            epi_load<BM, BN, MODE, VW>(e, rd, s1, m0, n0, tid, j0 + S::CH);
+            epi_finish<BM, BN, MODE, VW>(e, s0, ct, LDC, tid, j0, bias4);
+            if (j0 + 2 * S::CH < S::ITEMS) epi_load<BM, BN, MODE, VW>(e, rd, s0, m0, n0, tid, j0 + 2 * S::CH);
+            epi_finish<BM, BN, MODE, VW>(e, s1, ct, LDC, tid, j0 + S::CH, bias4);
+        }
+    }
+}
+
+// wave-uniform dispatch over the row mode at a fixed vector width
+#define C1V_EPI_DISPATCH(VWV, CALL)                                                      \
+    switch (p.e.row_mode) {                                                              \
+        case C1V_ROW_STORE:   { constexpr int MODE_ = C1V_ROW_STORE;   constexpr int VW_ = VWV; CALL; } break; \
+        case C1V_ROW_POOL2:   { constexpr int MODE_ = C1V_ROW_POOL2;   constexpr int VW_ = VWV; CALL; } break; \
+        case C1V_ROW_UP2:     { constexpr int MODE_ = C1V_ROW_UP2;     constexpr int VW_ = VWV; CALL; } break; \
+        case C1V_ROW_PAIRSUM: { constexpr int MODE_ = C1V_ROW_PAIRSUM; constexpr int VW_ = VWV; CALL; } break; \
+        default:              { constexpr int MODE_ = C1V_ROW_UNPOOL;  constexpr int VW_ = VWV; CALL; } break; \
+    }
+
 #ifdef NT_STAMP
 // diagnostic build only: cycle stamps of wave 0 of every workgroup (start, after prologue, after K loop, end)
-__device__ unsigned long long nt_dbg[8 * 8192];
+__device__ unsigned long long nt_dbg[16 * 8192];
 extern "C" int c1v_debug_read_nt(unsigned long long* dst, int n) {
     return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(nt_dbg), sizeof(unsigned long long) * n);
 }
@@ -216,7 +437,7 @@ extern "C" int c1v_debug_read_nt(unsigned long long* dst, int n) {
 template <typename T, int BM, int BN, int NS>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(const NtParams p) {
 #ifdef NT_STAMP
-    unsigned long long stamp[8];
+    unsigned long long stamp[16];
 #endif
     NT_T(0);
     constexpr int WTM = BM / 2, WTN = BN / 2, MI = WTM / 16, NJ = WTN / 16;
@@ -234,12 +455,12 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const NtParams p) {
     // chunk lpos ^ ((row>>1)&7) of that row (same 128-byte line, so coalescing is unchanged)
     const char* ap[A_IT];
     const char* bp[B_IT];
+    const RowDiv rd = make_rowdiv(m0, p.e.Le);
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
         const int row = lrow + i * 32;
-        int m = m0 + row;
-        if (m >= p.e.M) m = p.e.M - 1;
-        const int b = m / p.e.Le, u = m - b * p.e.Le;
+        int b, u;
+        rowdiv(rd, m0 + row < p.e.M ? row : p.e.M - 1 - m0, b, u);
         ap[i] = p.A + (int64_t)b * p.a_bstride_b + (int64_t)(p.a_off + u) * p.lda_b + ((lpos ^ ((row >> 1) & 7)) << 4);
     }
 #pragma unroll
@@ -250,6 +471,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const NtParams p) {
         bp[i] = p.W + (int64_t)n * p.ldw_b + ((lpos ^ ((row >> 1) & 7)) << 4);
     }
     const int KT = (int)((p.Kb + 127) / 128);
+    NT_T(8);
 
     auto issue = [&](int kt) {
         char* sa = smem + (kt % NS) * STAGE + wave * 1024;
@@ -270,13 +492,30 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const NtParams p) {
 #pragma unroll
     for (int s = 0; s < NS - 1; ++s)
         if (s < KT) issue(s);
+    NT_T(9);
     // bias of this thread's epilogue channel group (see epilogue_rows): requested now, consumed after the K loop
-    float bias4[4];
+    float bias4[4] = {0.f, 0.f, 0.f, 0.f};
+    const int fastw = p.e.fastw;                       // wave-uniform: 4 / 2 = vectorised epilogue, 0 = element-wise
+    EpiState es;
     {
         const int nbias = n0 + 4 * (tid % (BN / 4));
+        if (p.e.bias) {
+            if (fastw == 4) {
+                if (nbias < p.e.N) { const float4 b = *(const float4*)(p.e.bias + nbias); bias4[0] = b.x; bias4[1] = b.y; bias4[2] = b.z; bias4[3] = b.w; }
+            } else if (fastw == 2) {
+                if (nbias < p.e.N) { const float2 b = *(const float2*)(p.e.bias + nbias); bias4[0] = b.x; bias4[1] = b.y; }
+                if (nbias + 2 < p.e.N) { const float2 b = *(const float2*)(p.e.bias + nbias + 2); bias4[2] = b.x; bias4[3] = b.y; }
+            } else {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) bias4[k] = (p.e.bias && nbias + k < p.e.N) ? p.e.bias[nbias + k] : 0.0f;
+                for (int k = 0; k < 4; ++k) bias4[k] = nbias + k < p.e.N ? p.e.bias[nbias + k] : 0.0f;
+            }
+        }
     }
+    NT_T(10);
+    // epilogue inputs of the first chunk of rows (older than every K tile but the first NS-1: the counted waits below
+    // stay valid because loads return in order -- they only wait a little longer at kt = 0)
+    if (fastw == 4) { C1V_EPI_DISPATCH(4, (epi_load<BM, BN, MODE_, VW_>(p.e, rd, es, m0, n0, tid, 0))) }
+    else if (fastw == 2) { C1V_EPI_DISPATCH(2, (epi_load<BM, BN, MODE_, VW_>(p.e, rd, es, m0, n0, tid, 0))) }
     NT_T(1);
 
     for (int kt = 0; kt < KT; ++kt) {
@@ -321,30 +560,23 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const NtParams p) {
                 ct[(wm * WTM + i * 16 + (lane >> 4) * 4 + r) * LDC + wn * WTN + j * 16 + (lane & 15)] = acc[i][j][r];
     __syncthreads();
     NT_T(5);
-    switch (p.e.row_mode) {                            // wave-uniform; one specialised epilogue each
-        case C1V_ROW_STORE:   epilogue_rows<BM, BN, C1V_ROW_STORE>(p.e, ct, LDC, m0, n0, tid, bias4); break;
-        case C1V_ROW_POOL2:   epilogue_rows<BM, BN, C1V_ROW_POOL2>(p.e, ct, LDC, m0, n0, tid, bias4); break;
-        case C1V_ROW_UP2:     epilogue_rows<BM, BN, C1V_ROW_UP2>(p.e, ct, LDC, m0, n0, tid, bias4); break;
-        case C1V_ROW_PAIRSUM: epilogue_rows<BM, BN, C1V_ROW_PAIRSUM>(p.e, ct, LDC, m0, n0, tid, bias4); break;
-        default:              epilogue_rows<BM, BN, C1V_ROW_UNPOOL>(p.e, ct, LDC, m0, n0, tid, bias4); break;
+    if (fastw == 4) { C1V_EPI_DISPATCH(4, (epi_fast_rows<BM, BN, MODE_, VW_>(p.e, rd, es, ct, LDC, m0, n0, tid, bias4))) }
+    else if (fastw == 2) { C1V_EPI_DISPATCH(2, (epi_fast_rows<BM, BN, MODE_, VW_>(p.e, rd, es, ct, LDC, m0, n0, tid, bias4))) }
+    else {
+        switch (p.e.row_mode) {                        // wave-uniform; one specialised epilogue each
+            case C1V_ROW_STORE:   epilogue_rows<BM, BN, C1V_ROW_STORE>(p.e, ct, LDC, m0, n0, tid, bias4); break;
+            case C1V_ROW_POOL2:   epilogue_rows<BM, BN, C1V_ROW_POOL2>(p.e, ct, LDC, m0, n0, tid, bias4); break;
+            case C1V_ROW_UP2:     epilogue_rows<BM, BN, C1V_ROW_UP2>(p.e, ct, LDC, m0, n0, tid, bias4); break;
+            case C1V_ROW_PAIRSUM: epilogue_rows<BM, BN, C1V_ROW_PAIRSUM>(p.e, ct, LDC, m0, n0, tid, bias4); break;
+            default:              epilogue_rows<BM, BN, C1V_ROW_UNPOOL>(p.e, ct, LDC, m0, n0, tid, bias4); break;
+        }
     }
 #ifdef NT_STAMP
     NT_T(6);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     NT_T(3);
-#ifdef NT_TWICE
-    // diagnostic: the same epilogue a second time (same values stored again) -- hot instruction cache, hot data
-    switch (p.e.row_mode) {                            // wave-uniform; one specialised epilogue each
-        case C1V_ROW_STORE:   epilogue_rows<BM, BN, C1V_ROW_STORE>(p.e, ct, LDC, m0, n0, tid, bias4); break;
-        case C1V_ROW_POOL2:   epilogue_rows<BM, BN, C1V_ROW_POOL2>(p.e, ct, LDC, m0, n0, tid, bias4); break;
-        case C1V_ROW_UP2:     epilogue_rows<BM, BN, C1V_ROW_UP2>(p.e, ct, LDC, m0, n0, tid, bias4); break;
-        case C1V_ROW_PAIRSUM: epilogue_rows<BM, BN, C1V_ROW_PAIRSUM>(p.e, ct, LDC, m0, n0, tid, bias4); break;
-        default:              epilogue_rows<BM, BN, C1V_ROW_UNPOOL>(p.e, ct, LDC, m0, n0, tid, bias4); break;
-    }
-    NT_T(7);
-#endif
     const int wg = blockIdx.x + gridDim.x * blockIdx.y;
-    if (tid == 0 && wg < 8192) for (int i = 0; i < 8; ++i) nt_dbg[wg * 8 + i] = stamp[i];
+    if (tid == 0 && wg < 8192) for (int i = 0; i < 12; ++i) nt_dbg[wg * 16 + i] = stamp[i];
 #endif
 }
 
@@ -523,6 +755,12 @@ template <typename T> static int launch_nt_t(const NtParams& p, hipStream_t st) 
         static bool once = (set_lds(gemm_nt_kernel<T, 128, 128, NS>, LDS), true); (void)once;
         dim3 grid((unsigned)c1v_cdiv(p.e.M, 128), (unsigned)c1v_cdiv(p.e.N, 128));
         hipLaunchKernelGGL((gemm_nt_kernel<T, 128, 128, NS>), grid, dim3(256), LDS, st, p);
+    } else if (c1v_cdiv(p.Kb, 128) >= 8) {
+        // long K, few workgroups: latency-bound -- a deep ring (7 K tiles = 112 KiB in flight per CU) instead of occupancy
+        constexpr int NS = 8, LDS = NS * 128 * 128;
+        static bool once = (set_lds(gemm_nt_kernel<T, 64, 64, NS>, LDS), true); (void)once;
+        dim3 grid((unsigned)c1v_cdiv(p.e.M, 64), (unsigned)c1v_cdiv(p.e.N, 64));
+        hipLaunchKernelGGL((gemm_nt_kernel<T, 64, 64, NS>), grid, dim3(256), LDS, st, p);
     } else {
         constexpr int NS = 4, LDS = NS * 128 * 128;
         static bool once = (set_lds(gemm_nt_kernel<T, 64, 64, NS>, LDS), true); (void)once;
@@ -573,5 +811,22 @@ int c1v_fill_epi(const c1v_epilogue& e, EpiDev& d, int M, int Le, int nrows, int
     C1V_REQUIRE(e.reshape_w <= 0 || (e.row_mode == C1V_ROW_STORE || e.row_mode == C1V_ROW_UNPOOL), "reshape_w only with STORE/UNPOOL");
     const int c_max = e.reshape_w > 0 ? e.reshape_w : N;
     C1V_REQUIRE(c_max <= e.dst.cp, "destination row pitch %d is smaller than %d channels", e.dst.cp, c_max);
+    // widest vector width at which every 4-channel group of the epilogue stays aligned (see epi_load / epi_finish)
+    d.fastw = 0;
+    const bool masks = e.sel != nullptr || e.keep != nullptr;
+    for (int vw = 4; vw >= 2 && d.fastw == 0; vw -= 2) {
+        auto al = [&](const void* p, int esize) { return ((uintptr_t)p % (uintptr_t)(vw * esize)) == 0; };
+        bool ok = N % vw == 0 && (e.reshape_w <= 0 || e.reshape_w % 4 == 0);
+        ok = ok && al(e.dst.data, c1v_esize(e.dst.dtype)) && e.dst.bstride % vw == 0 && e.dst.cp % vw == 0;
+        ok = ok && (e.bias == nullptr || al(e.bias, 4));
+        if (e.act.data) ok = ok && al(e.act.data, c1v_esize(e.act.dtype)) && e.act.bstride % vw == 0 && e.act.cp % vw == 0;
+        if (masks) {
+            const int64_t n_samples = c1v_cdiv(M, Le > 0 ? Le : 1);
+            ok = ok && e.sel_bstride % vw == 0 && e.sel_cp % vw == 0 && n_samples * e.sel_bstride + e.sel_cp < (int64_t)1 << 31;
+            ok = ok && (e.sel == nullptr || al(e.sel, 1)) && (e.keep == nullptr || al(e.keep, 1));
+        }
+        if (ok) d.fastw = vw;
+    }
+    if (const char* env = getenv("C1V_EPI_ELEMENTWISE")) if (env[0] == '1') d.fastw = 0;     // diagnostic: force the element-wise path
     return 0;
 }
