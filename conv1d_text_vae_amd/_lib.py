@@ -48,6 +48,10 @@ class WgradArgs(C.Structure):
                 ('bias_out', C.c_void_p), ('bias_slab_stride', C.c_int64)]
 
 
+class BwdPairArgs(C.Structure):
+    _fields_ = [('conv_dgrad', C.POINTER(ConvArgs)), ('dense_dgrad', C.POINTER(DenseArgs)), ('wgrad', C.POINTER(WgradArgs))]
+
+
 class ColsumArgs(C.Structure):
     _fields_ = [('buf', C.c_void_p), ('dtype', C.c_int32), ('rows', C.c_int64), ('ld', C.c_int64), ('C', C.c_int32),
                 ('out', C.c_void_p), ('slab_stride', C.c_int64), ('splits', C.c_int32)]
@@ -141,6 +145,7 @@ SYMBOLS = {
     'c1v_conv1d_wgrad': ([_P(WgradArgs), C.c_void_p], C.c_int),
     'c1v_deconv1d_wgrad': ([_P(WgradArgs), C.c_void_p], C.c_int),
     'c1v_dense_wgrad': ([_P(WgradArgs), C.c_void_p], C.c_int),
+    'c1v_bwd_pair': ([_P(BwdPairArgs), C.c_void_p], C.c_int),
     'c1v_colsum': ([_P(ColsumArgs), C.c_void_p], C.c_int),
     'c1v_pack_weights': ([C.c_void_p, C.c_int32, C.c_int32, C.c_void_p], C.c_int),
     'c1v_pack_input': ([_P(PackInputArgs), C.c_void_p], C.c_int),

@@ -42,7 +42,7 @@ static int check_operand_seq(const c1v_seq& s, const char* what) {
 }
 
 // ---- conv / deconv forward and dgrad ------------------------------------------------------------------
-static int conv_common(const c1v_conv1d_args* a, void* stream, const char* what) {
+static int conv_params(const c1v_conv1d_args* a, const char* what, NtParams& p) {
     C1V_REQUIRE(a && a->w_op, "%s: null argument", what);
     if (check_operand_seq(a->x, what)) return -1;
     C1V_REQUIRE(a->k > 0 && a->n_rows > 0 && a->n_out > 0 && a->a_off >= 0, "%s: bad shape k=%d n_rows=%d n_out=%d", what, a->k, a->n_rows, a->n_out);
@@ -53,13 +53,17 @@ static int conv_common(const c1v_conv1d_args* a, void* stream, const char* what)
     const int Le = pairs ? ((a->n_rows + 1) & ~1) : a->n_rows;
     C1V_REQUIRE(a->a_off + Le + a->k - 1 <= pitch + C1V_SLACK_ROWS, "%s: padded row enumeration overruns the sample pitch", what);
     const int es = c1v_esize(a->x.dtype);
-    NtParams p{};
+    p = NtParams{};
     p.A = (const char*)a->x.data; p.a_bstride_b = a->x.bstride * es; p.lda_b = (int64_t)a->x.cp * es; p.a_off = a->a_off;
     p.W = (const char*)a->w_op; p.ldw_b = a->ldw * es; p.Kb = (int64_t)a->k * a->x.cp * es;
     C1V_REQUIRE(a->ldw >= (int64_t)a->k * a->x.cp, "%s: ldw (%lld) is smaller than k*cp", what, (long long)a->ldw);
     const int64_t M = (int64_t)a->x.batch * Le;
     C1V_REQUIRE(M < (1ll << 31), "%s: too many rows", what);
-    if (c1v_fill_epi(a->epi, p.e, (int)M, Le, a->n_rows, a->n_out)) return -1;
+    return c1v_fill_epi(a->epi, p.e, (int)M, Le, a->n_rows, a->n_out);
+}
+static int conv_common(const c1v_conv1d_args* a, void* stream, const char* what) {
+    NtParams p;
+    if (conv_params(a, what, p)) return -1;
     return c1v_launch_nt(a->x.dtype, p, (hipStream_t)stream);
 }
 extern "C" int c1v_conv1d_fwd(const c1v_conv1d_args* a, void* s) { return conv_common(a, s, "conv1d_fwd"); }
@@ -72,24 +76,28 @@ extern "C" int c1v_deconv1d_fwd(const c1v_conv1d_args* a, void* s) {
 extern "C" int c1v_deconv1d_dgrad(const c1v_conv1d_args* a, void* s) { return conv_common(a, s, "deconv1d_dgrad"); }
 
 // ---- dense forward / dgrad -----------------------------------------------------------------------------
-static int dense_common(const c1v_dense_args* a, void* stream, const char* what) {
+static int dense_params(const c1v_dense_args* a, const char* what, NtParams& p) {
     C1V_REQUIRE(a && a->a && a->w_op, "%s: null argument", what);
     C1V_REQUIRE(a->dtype == C1V_F32 || a->dtype == C1V_BF16, "%s: bad dtype", what);
     C1V_REQUIRE(a->rows > 0 && a->K > 0 && a->n_out > 0 && a->lda >= a->K && a->ldw >= a->K, "%s: bad shape rows=%d K=%d n_out=%d", what, a->rows, a->K, a->n_out);
     const int es = c1v_esize(a->dtype);
     C1V_REQUIRE((a->K * es) % 16 == 0, "%s: K (%d) must be a whole number of 16-byte chunks", what, a->K);
-    NtParams p{};
+    p = NtParams{};
     p.A = (const char*)a->a; p.a_bstride_b = a->lda * es; p.lda_b = a->lda * es; p.a_off = 0;
     p.W = (const char*)a->w_op; p.ldw_b = a->ldw * es; p.Kb = (int64_t)a->K * es;
     C1V_REQUIRE(a->epi.row_mode == C1V_ROW_STORE || a->epi.row_mode == C1V_ROW_UNPOOL, "%s: dense epilogue supports STORE / UNPOOL only", what);
-    if (c1v_fill_epi(a->epi, p.e, a->rows, 1, 1, a->n_out)) return -1;
+    return c1v_fill_epi(a->epi, p.e, a->rows, 1, 1, a->n_out);
+}
+static int dense_common(const c1v_dense_args* a, void* stream, const char* what) {
+    NtParams p;
+    if (dense_params(a, what, p)) return -1;
     return c1v_launch_nt(a->dtype, p, (hipStream_t)stream);
 }
 extern "C" int c1v_dense_fwd(const c1v_dense_args* a, void* s) { return dense_common(a, s, "dense_fwd"); }
 extern "C" int c1v_dense_dgrad(const c1v_dense_args* a, void* s) { return dense_common(a, s, "dense_dgrad"); }
 
 // ---- wgrad -------------------------------------------------------------------------------------------------
-extern "C" int c1v_wgrad(const c1v_wgrad_args* a, void* stream) {
+static int wgrad_params(const c1v_wgrad_args* a, TnParams& p) {
     C1V_REQUIRE(a && a->a && a->d && a->out, "wgrad: null argument");
     C1V_REQUIRE(a->dtype == C1V_F32 || a->dtype == C1V_BF16, "wgrad: bad dtype");
     C1V_REQUIRE(a->I > 0 && a->J > 0 && a->I <= a->lda && a->J <= a->ldd, "wgrad: bad shape I=%d J=%d", a->I, a->J);
@@ -97,7 +105,7 @@ extern "C" int c1v_wgrad(const c1v_wgrad_args* a, void* stream) {
     C1V_REQUIRE(a->r_begin + a->a_shift0 >= 0, "wgrad: first A row would be negative");
     const int es = c1v_esize(a->dtype);
     const int per16 = 16 / es;
-    TnParams p{};
+    p = TnParams{};
     p.A = (const char*)a->a; p.lda_b = a->lda * es; p.I = a->I; p.Ia = (int)(c1v_cdiv(a->I, per16) * per16);
     p.D = (const char*)a->d; p.ldd_b = a->ldd * es; p.J = a->J; p.Ja = (int)(c1v_cdiv(a->J, per16) * per16);
     C1V_REQUIRE(p.Ia <= a->lda && p.Ja <= a->ldd, "wgrad: rows must be padded to 16-byte chunks");
@@ -107,7 +115,25 @@ extern "C" int c1v_wgrad(const c1v_wgrad_args* a, void* stream) {
     p.a_shift0 = a->a_shift0; p.taps = a->taps; p.flip = a->flip; p.tap_stride = a->tap_stride; p.si = a->si; p.sj = a->sj;
     p.out = a->out; p.slab_stride = a->slab_stride; p.splits = a->splits;
     p.bias_out = a->bias_out; p.bias_slab_stride = a->bias_slab_stride;
+    return 0;
+}
+extern "C" int c1v_wgrad(const c1v_wgrad_args* a, void* stream) {
+    TnParams p;
+    if (wgrad_params(a, p)) return -1;
     return c1v_launch_tn(a->dtype, p, (hipStream_t)stream);
+}
+
+// ---- one backward stage in one launch: dgrad (conv / deconv / dense) + wgrad of the same dO buffer ------------
+extern "C" int c1v_bwd_pair(const c1v_bwd_pair_args* a, void* stream) {
+    C1V_REQUIRE(a && a->wgrad && ((a->conv_dgrad != nullptr) != (a->dense_dgrad != nullptr)), "bwd_pair: needs a wgrad and exactly one dgrad");
+    NtParams nt;
+    TnParams tn;
+    int dtype;
+    if (a->conv_dgrad) { if (conv_params(a->conv_dgrad, "bwd_pair dgrad", nt)) return -1; dtype = a->conv_dgrad->x.dtype; }
+    else { if (dense_params(a->dense_dgrad, "bwd_pair dgrad", nt)) return -1; dtype = a->dense_dgrad->dtype; }
+    if (wgrad_params(a->wgrad, tn)) return -1;
+    C1V_REQUIRE(dtype == a->wgrad->dtype, "bwd_pair: dgrad and wgrad operand types differ");
+    return c1v_launch_pair(dtype, nt, tn, (hipStream_t)stream);
 }
 extern "C" int c1v_conv1d_wgrad(const c1v_wgrad_args* a, void* s) { return c1v_wgrad(a, s); }
 extern "C" int c1v_deconv1d_wgrad(const c1v_wgrad_args* a, void* s) { return c1v_wgrad(a, s); }

@@ -100,4 +100,7 @@ struct TnParams {
 
 int c1v_launch_nt(int dtype, const NtParams& p, hipStream_t st);
 int c1v_launch_tn(int dtype, const TnParams& p, hipStream_t st);
+int c1v_launch_pair(int dtype, const NtParams& nt, const TnParams& tn, hipStream_t st);
+int c1v_check_nt(const NtParams& p);
+int c1v_check_tn(const TnParams& p);
 int c1v_fill_epi(const c1v_epilogue& e, EpiDev& d, int M, int Le, int nrows, int N);

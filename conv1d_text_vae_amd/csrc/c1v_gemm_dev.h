@@ -1,0 +1,755 @@
+// MFMA GEMM engine of libc1dvae (gfx950): every GEMM-shaped op of the VAE goes through one of two kernels.
+//
+//   gemm_nt : C[m][n] = sum_k A[m][k] * W[n][k]      conv / deconv / dense forward and dgrad (implicit GEMM:
+//             a conv window over a channels-last buffer IS a contiguous K = k*cp run, so conv = GEMM with
+//             overlapping A rows, lda = cp), with the fused epilogue of c1v_epilogue.
+//   gemm_tn : C[i][j] = sum_r A[r][i] * D[r][j]      wgrad, split over r into fp32 slabs; optionally also the
+//             column sums of D (bias gradient) through one extra all-ones MFMA operand.
+//
+// Both are 256 threads = 4 waves (2x2) and written once for "16 bytes of K per lane": bf16 feeds one
+// v_mfma_f32_16x16x32_bf16 per 16-byte fragment pair, fp32 feeds four v_mfma_f32_16x16x4_f32 (exact fp32 FMA chain) --
+// the k permutation inside a fragment is the same for both operands, so the sum is unchanged.
+//
+// Staging: operand tiles go global -> LDS by LDS-DMA (global_load_lds_dwordx4, no VGPR staging) into a ring of NS
+// stages; a counted s_waitcnt vmcnt leaves NS-2 tiles in flight across the single barrier per K step.  At the shapes
+// of this model (M = batch*seq of a few thousand rows, K a few hundred) the GEMMs are latency- not MFMA-bound, so the
+// depth of the ring, not the MFMA schedule, is what sets their time.  LDS-DMA writes are lane-linear, therefore
+// swizzles are applied to the per-lane SOURCE address and padding lanes read a dummy address.
+// No load is predicated: out-of-range rows are clamped (their results are masked in the epilogue) and the K / row
+// tails rely on zero padding of the operand buffers (documented in include/c1dvae.h).
+#pragma once
+#include "c1v_common.h"
+
+// ------------------------------------------------------------------------------------------------------
+// fragment MMA: 16 bytes of K per lane
+// ------------------------------------------------------------------------------------------------------
+template <typename T> __device__ __forceinline__ void mma16(f32x4_t& acc, const uint4& a, const uint4& b);
+template <> __device__ __forceinline__ void mma16<bf16_raw>(f32x4_t& acc, const uint4& a, const uint4& b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
+}
+template <> __device__ __forceinline__ void mma16<float>(f32x4_t& acc, const uint4& a, const uint4& b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
+}
+
+__device__ __forceinline__ void glds16(const char* src, char* lds_wave_base) { c1v_glds16(src, c1v_lds_addr(lds_wave_base)); }
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void block_barrier() {
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+// LDS image of an NT operand tile: 128-byte rows (64 bf16 / 32 fp32 of K), 16-byte chunk index XOR-swizzled with
+// (row>>1)&7 so that the 16 lanes of a ds_read_b128 group (rows r..r+15, one chunk column) hit 16 distinct slots.
+__device__ __forceinline__ int lds_off(int row, int ch) { return row * 128 + ((ch ^ ((row >> 1) & 7)) << 4); }
+
+// ------------------------------------------------------------------------------------------------------
+// NT kernel
+// ------------------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------------------
+// fused epilogue (c1v_epilogue in include/c1dvae.h) over a tile parked in LDS
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void store4(const EpiDev& e, int64_t idx, const float v[4], int count) {
+    // `count` leading values are stored; one 8- / 16-byte store when all four are and the address allows it
+    if (count == 4) {
+        if (e.dst_dtype == C1V_F32) {
+            float* d = (float*)e.dst + idx;
+            if ((((uintptr_t)d) & 15) == 0) { *(float4*)d = make_float4(v[0], v[1], v[2], v[3]); return; }
+        } else {
+            bf16_raw* d = (bf16_raw*)e.dst + idx;
+            if ((((uintptr_t)d) & 7) == 0) { *(uint2*)d = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])); return; }
+        }
+    }
+    for (int k = 0; k < count; ++k) store_any(e.dst, e.dst_dtype, idx + k, v[k]);
+}
+
+// A thread owns ONE 4-channel group (g = tid % G) of every (256/G)-th tile row, so its bias values are loaded once -- by
+// the kernel, before the K loop, where the latency is free -- and its rows are processed in chunks of up to four: first
+// the mask / dropout / pool bytes of the whole chunk are requested, then values are formed and stored (a rolled
+// one-row-per-iteration loop serialised one global-load latency per row, ~1.5 us each).
+template <int BM, int BN, int MODE>
+__device__ __forceinline__ void epilogue_rows(const EpiDev& e, const float* ct, int LDC, int m0, int n0, int tid, const float bias4[4]) {
+    constexpr bool PAIRS = MODE == C1V_ROW_POOL2 || MODE == C1V_ROW_PAIRSUM;
+    constexpr int G = BN / 4, RPI = 256 / G, ROWS = PAIRS ? BM / 2 : BM, ITEMS = ROWS / RPI, CH = ITEMS < 4 ? ITEMS : 4;
+    static_assert(256 % G == 0 && ROWS % RPI == 0 && ITEMS % CH == 0, "tile shape");
+    const int g = tid % G, r0 = tid / G;
+    const int n = n0 + 4 * g;
+    if (n >= e.N) return;
+    const int cnt = e.N - n < 4 ? e.N - n : 4;                      // valid channels of this group
+    int tn = 0, c = n;
+    if (e.reshape_w > 0) { tn = n / e.reshape_w; c = n - tn * e.reshape_w; }
+    const bool straddle = e.reshape_w > 0 && c + cnt > e.reshape_w;  // group crosses a (t, c) row boundary: element-wise
+    constexpr int mode = MODE;                        // compile-time: every mode test below folds away
+#pragma unroll 1
+    for (int j0 = 0; j0 < ITEMS; j0 += CH) {
+        bool ok[CH];
+        int bb[CH], uu[CH], tt[CH];
+        float am[CH][4];
+        uint8_t by[CH][4];
+#pragma unroll
+        for (int jj = 0; jj < CH; ++jj) {
+            const int rr = r0 + (j0 + jj) * RPI;
+            const int m = m0 + (PAIRS ? 2 * rr : rr);
+            const int mm = m < e.M ? m : e.M - 1;
+            const int b = mm / e.Le, u = mm - b * e.Le;
+            const int t = e.reshape_w > 0 ? tn : (PAIRS ? (u >> 1) : u);
+            bool o = m < e.M;
+            if (mode == C1V_ROW_STORE) o = o && u < e.nrows && t < e.dst_len;
+            else if (mode == C1V_ROW_UP2) o = o && u < e.nrows && 2 * t < e.dst_len;
+            else if (mode == C1V_ROW_UNPOOL) o = o && u < e.nrows && 2 * t + 1 < e.dst_len;
+            else if (mode == C1V_ROW_POOL2) o = o && t < e.dst_len && u + 1 < e.nrows;
+            else o = o && t < e.dst_len;
+            ok[jj] = o; bb[jj] = b; uu[jj] = u; tt[jj] = t;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { am[jj][k] = 1.0f; by[jj][k] = 1; }
+            if (o && !straddle) {
+                if (e.act && mode != C1V_ROW_UP2 && mode != C1V_ROW_POOL2) {
+                    const int64_t ai = (int64_t)b * e.act_bstride + (int64_t)(e.act_off + t * e.act_rowmul) * e.act_cp + c;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) if (k < cnt) am[jj][k] = load_any(e.act, e.act_dtype, ai + k);
+                }
+                const int64_t si = (int64_t)b * e.sel_bstride + (int64_t)t * e.sel_cp + c;
+                if (mode == C1V_ROW_UNPOOL) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) if (k < cnt) by[jj][k] = e.sel[si + k];
+                } else if (e.keep && (mode == C1V_ROW_STORE || mode == C1V_ROW_POOL2)) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) if (k < cnt) by[jj][k] = e.keep[si + k];
+                }
+            }
+        }
+#pragma unroll
+        for (int jj = 0; jj < CH; ++jj) {
+            if (!ok[jj]) continue;
+            const int rr = r0 + (j0 + jj) * RPI;
+            const int row = PAIRS ? 2 * rr : rr;
+            const int b = bb[jj], u = uu[jj], t = tt[jj];
+            const float4 q0 = *(const float4*)(ct + row * LDC + 4 * g);
+            float v[4] = {q0.x, q0.y, q0.z, q0.w};
+            float w[4] = {0.f, 0.f, 0.f, 0.f};
+            if (PAIRS) { const float4 q1 = *(const float4*)(ct + (row + 1) * LDC + 4 * g); w[0] = q1.x; w[1] = q1.y; w[2] = q1.z; w[3] = q1.w; }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                v[k] += bias4[k]; w[k] += bias4[k];
+                if (e.relu) { v[k] = fmaxf(v[k], 0.0f); w[k] = fmaxf(w[k], 0.0f); }
+                if (e.exp2) v[k] = exp2f(v[k]);
+                am[jj][k] = (e.act && mode != C1V_ROW_UP2 && mode != C1V_ROW_POOL2) ? (am[jj][k] > 0.0f ? e.act_scale : 0.0f) : 1.0f;
+            }
+            if (straddle) {
+                // element-wise (t, c) = divmod(n + k, reshape_w); only dense layers whose width is not a multiple of 4
+                for (int k = 0; k < cnt; ++k) {
+                    const int te = (n + k) / e.reshape_w, ce = (n + k) - te * e.reshape_w;
+                    float x = v[k];
+                    if (mode == C1V_ROW_STORE) {
+                        if (te >= e.dst_len) continue;
+                        if (e.act) x *= load_any(e.act, e.act_dtype, (int64_t)b * e.act_bstride + (int64_t)(e.act_off + te * e.act_rowmul) * e.act_cp + ce) > 0.0f ? e.act_scale : 0.0f;
+                        if (e.keep) x = e.keep[(int64_t)b * e.sel_bstride + (int64_t)te * e.sel_cp + ce] ? x * e.keep_scale : 0.0f;
+                        store_any(e.dst, e.dst_dtype, (int64_t)b * e.dst_bstride + (int64_t)(e.dst_off + te) * e.dst_cp + ce, x);
+                    } else {   // UNPOOL
+                        if (2 * te + 1 >= e.dst_len) continue;
+                        if (e.act) x *= load_any(e.act, e.act_dtype, (int64_t)b * e.act_bstride + (int64_t)(e.act_off + te * e.act_rowmul) * e.act_cp + ce) > 0.0f ? e.act_scale : 0.0f;
+                        const int sidx = e.sel[(int64_t)b * e.sel_bstride + (int64_t)te * e.sel_cp + ce] ? 1 : 0;
+                        const int64_t d = (int64_t)b * e.dst_bstride + (int64_t)(e.dst_off + 2 * te) * e.dst_cp + ce;
+                        store_any(e.dst, e.dst_dtype, d + (int64_t)sidx * e.dst_cp, x);
+                        store_any(e.dst, e.dst_dtype, d + (int64_t)(1 - sidx) * e.dst_cp, 0.0f);
+                    }
+                }
+                continue;
+            }
+            const int64_t si = (int64_t)b * e.sel_bstride + (int64_t)t * e.sel_cp + c;
+            if (mode == C1V_ROW_STORE) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    v[k] *= am[jj][k];
+                    if (e.keep) v[k] = by[jj][k] ? v[k] * e.keep_scale : 0.0f;
+                }
+                store4(e, (int64_t)b * e.dst_bstride + (int64_t)(e.dst_off + t) * e.dst_cp + c, v, cnt);
+            } else if (mode == C1V_ROW_UP2) {
+                const int64_t d = (int64_t)b * e.dst_bstride + (int64_t)(e.dst_off + 2 * t) * e.dst_cp + c;
+                store4(e, d, v, cnt);
+                if (2 * t + 1 < e.dst_len) store4(e, d + e.dst_cp, v, cnt);
+            } else if (mode == C1V_ROW_UNPOOL) {
+                float hi[4], lo[4];                                  // row 2t and row 2t+1
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const bool s1 = k < cnt && by[jj][k] != 0;
+                    const float x = v[k] * am[jj][k];
+                    hi[k] = s1 ? 0.0f : x; lo[k] = s1 ? x : 0.0f;
+                }
+                const int64_t d = (int64_t)b * e.dst_bstride + (int64_t)(e.dst_off + 2 * t) * e.dst_cp + c;
+                store4(e, d, hi, cnt);
+                store4(e, d + e.dst_cp, lo, cnt);
+            } else if (mode == C1V_ROW_POOL2) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const bool s1 = w[k] > v[k];                    // first maximum wins ties
+                    float x = s1 ? w[k] : v[k];
+                    if (k < cnt) {
+                        if (e.sel) e.sel[si + k] = s1 ? 1 : 0;
+                        if (e.keep) x = by[jj][k] ? x * e.keep_scale : 0.0f;
+                    }
+                    v[k] = x;
+                }
+                store4(e, (int64_t)b * e.dst_bstride + (int64_t)(e.dst_off + t) * e.dst_cp + c, v, cnt);
+            } else {   // PAIRSUM
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = ((u < e.nrows ? v[k] : 0.0f) + (u + 1 < e.nrows ? w[k] : 0.0f)) * am[jj][k];
+                store4(e, (int64_t)b * e.dst_bstride + (int64_t)(e.dst_off + t) * e.dst_cp + c, v, cnt);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// vectorised epilogue (EpiDev::fastw = 4 or 2, decided on the host by c1v_fill_epi): every address a 4-channel group
+// touches is a multiple of VW elements, so activations / mask bytes / results move as whole 4-, 8- or 16-byte words and
+// nothing is branched per element.  The inputs of the first chunk of rows are requested BEFORE the K loop (their
+// latency hides behind it); the row -> (sample, step) split uses one scalar division per workgroup (RowDiv).
+// ------------------------------------------------------------------------------------------------------
+struct RowDiv { int Le, b0, u0; float rcp; };
+__device__ __forceinline__ RowDiv make_rowdiv(int m0, int Le) {
+    RowDiv d;
+    d.Le = Le; d.b0 = m0 / Le; d.u0 = m0 - d.b0 * Le; d.rcp = 1.0f / (float)Le;
+    return d;
+}
+// (b, u) of row m0 + r, 0 <= r < 2^15: float estimate of the quotient, exact after one correction step
+__device__ __forceinline__ void rowdiv(const RowDiv& d, int r, int& b, int& u) {
+    const int x = d.u0 + r;
+    int q = (int)((float)x * d.rcp);
+    int rem = x - q * d.Le;
+    if (rem < 0) { --q; rem += d.Le; } else if (rem >= d.Le) { ++q; rem -= d.Le; }
+    b = d.b0 + q; u = rem;
+}
+
+struct EpiState {
+    static constexpr int CH = 4;
+    int64_t di[CH];        // destination element index of the group (row 2t for UP2 / UNPOOL)
+    int si[CH];            // index of the group's mask bytes (sel / keep)
+    uint4 act[CH];         // raw activation words: bf16 in .x .y, fp32 in .x .. .w
+    uint32_t by[CH];       // four mask bytes
+    uint32_t flags;        // 4 bits per row: 1 = stored, 2 = UP2: second row fits / PAIRSUM: first member valid, 4 = PAIRSUM: second member valid
+    int cnt;               // valid channels of the group (VW = 4: always 4; VW = 2: 2 or 4); 0 = thread idle
+};
+
+template <int VW> __device__ __forceinline__ uint4 epi_ld_act(const EpiDev& e, int64_t i, int cnt) {
+    uint4 r = make_uint4(0u, 0u, 0u, 0u);
+    if (e.act_dtype == C1V_F32) {
+        const float* p = (const float*)e.act + i;
+        if (VW == 4) r = *(const uint4*)p;
+        else { const uint2 a = *(const uint2*)p; r.x = a.x; r.y = a.y; if (cnt == 4) { const uint2 b = *(const uint2*)(p + 2); r.z = b.x; r.w = b.y; } }
+    } else {
+        const bf16_raw* p = (const bf16_raw*)e.act + i;
+        if (VW == 4) { const uint2 a = *(const uint2*)p; r.x = a.x; r.y = a.y; }
+        else { r.x = *(const uint32_t*)p; if (cnt == 4) r.y = *(const uint32_t*)(p + 2); }
+    }
+    return r;
+}
+template <int VW> __device__ __forceinline__ uint32_t epi_ld_bytes(const uint8_t* p, int cnt) {
+    if (VW == 4) return *(const uint32_t*)p;
+    uint32_t r = *(const uint16_t*)p;
+    r |= (cnt == 4 ? (uint32_t)*(const uint16_t*)(p + 2) : 0x0101u) << 16;
+    return r;
+}
+template <int VW> __device__ __forceinline__ void epi_st_bytes(uint8_t* p, uint32_t v, int cnt) {
+    if (VW == 4) { *(uint32_t*)p = v; return; }
+    *(uint16_t*)p = (uint16_t)v;
+    if (cnt == 4) *(uint16_t*)(p + 2) = (uint16_t)(v >> 16);
+}
+template <int VW> __device__ __forceinline__ void epi_st(const EpiDev& e, int64_t i, const float v[4], int cnt) {
+    if (e.dst_dtype == C1V_F32) {
+        float* d = (float*)e.dst + i;
+        if (VW == 4) *(float4*)d = make_float4(v[0], v[1], v[2], v[3]);
+        else { *(float2*)d = make_float2(v[0], v[1]); if (cnt == 4) *(float2*)(d + 2) = make_float2(v[2], v[3]); }
+    } else {
+        bf16_raw* d = (bf16_raw*)e.dst + i;
+        if (VW == 4) *(uint2*)d = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+        else { *(uint32_t*)d = pack_bf16x2(v[0], v[1]); if (cnt == 4) *(uint32_t*)(d + 2) = pack_bf16x2(v[2], v[3]); }
+    }
+}
+
+template <int BM, int BN, int MODE> struct EpiShape {
+    static constexpr bool PAIRS = MODE == C1V_ROW_POOL2 || MODE == C1V_ROW_PAIRSUM;
+    static constexpr int G = BN / 4, RPI = 256 / G, ROWS = PAIRS ? BM / 2 : BM, ITEMS = ROWS / RPI, CH = ITEMS < 4 ? ITEMS : 4;
+    static_assert(256 % G == 0 && ROWS % RPI == 0 && ITEMS % CH == 0 && (ITEMS == CH || ITEMS % (2 * CH) == 0), "tile shape");
+};
+
+template <int BM, int BN, int MODE, int VW>
+__device__ __forceinline__ void epi_load(const EpiDev& e, const RowDiv& rd, EpiState& st, int m0, int n0, int tid, int j0) {
+    using S = EpiShape<BM, BN, MODE>;
+    constexpr bool PAIRS = S::PAIRS;
+    constexpr int G = S::G, RPI = S::RPI, CH = S::CH;
+    constexpr bool USE_ACT = MODE != C1V_ROW_UP2 && MODE != C1V_ROW_POOL2;
+    const int g = tid % G, r0 = tid / G;
+    const int n = n0 + 4 * g;
+    st.flags = 0; st.cnt = 0;
+    if (n >= e.N) return;
+    const int cnt = (VW == 4 || e.N - n >= 4) ? 4 : 2;
+    st.cnt = cnt;
+    int tn = 0, c = n;
+    if (e.reshape_w > 0) { tn = n / e.reshape_w; c = n - tn * e.reshape_w; }
+#pragma unroll
+    for (int jj = 0; jj < CH; ++jj) {
+        const int rr = r0 + (j0 + jj) * RPI;
+        const int r = PAIRS ? 2 * rr : rr;
+        int b, u;
+        rowdiv(rd, r, b, u);
+        const int t = e.reshape_w > 0 ? tn : (PAIRS ? (u >> 1) : u);
+        bool o = m0 + r < e.M;
+        uint32_t f = 0;
+        if (MODE == C1V_ROW_STORE) o = o && u < e.nrows && t < e.dst_len;
+        else if (MODE == C1V_ROW_UP2) { o = o && u < e.nrows && 2 * t < e.dst_len; f = 2 * t + 1 < e.dst_len ? 2u : 0u; }
+        else if (MODE == C1V_ROW_UNPOOL) o = o && u < e.nrows && 2 * t + 1 < e.dst_len;
+        else if (MODE == C1V_ROW_POOL2) o = o && t < e.dst_len && u + 1 < e.nrows;
+        else { o = o && t < e.dst_len; f = (u < e.nrows ? 2u : 0u) | (u + 1 < e.nrows ? 4u : 0u); }
+        const int trow = (MODE == C1V_ROW_UP2 || MODE == C1V_ROW_UNPOOL) ? 2 * t : t;
+        st.di[jj] = (int64_t)b * e.dst_bstride + (int64_t)(e.dst_off + trow) * e.dst_cp + c;
+        st.si[jj] = (int)((int64_t)b * e.sel_bstride + (int64_t)t * e.sel_cp + c);
+        st.act[jj] = make_uint4(0u, 0u, 0u, 0u);
+        st.by[jj] = 0x01010101u;
+        if (o) {
+            st.flags |= (1u | f) << (4 * jj);
+            if (USE_ACT && e.act)
+                st.act[jj] = epi_ld_act<VW>(e, (int64_t)b * e.act_bstride + (int64_t)(e.act_off + t * e.act_rowmul) * e.act_cp + c, cnt);
+            if (MODE == C1V_ROW_UNPOOL) st.by[jj] = epi_ld_bytes<VW>(e.sel + st.si[jj], cnt);
+            else if (e.keep && (MODE == C1V_ROW_STORE || MODE == C1V_ROW_POOL2)) st.by[jj] = epi_ld_bytes<VW>(e.keep + st.si[jj], cnt);
+        }
+    }
+}
+
+template <int BM, int BN, int MODE, int VW>
+__device__ __forceinline__ void epi_finish(const EpiDev& e, const EpiState& st, const float* ct, int LDC, int tid, int j0, const float bias4[4]) {
+    using S = EpiShape<BM, BN, MODE>;
+    constexpr bool PAIRS = S::PAIRS;
+    constexpr int G = S::G, RPI = S::RPI, CH = S::CH;
+    constexpr bool USE_ACT = MODE != C1V_ROW_UP2 && MODE != C1V_ROW_POOL2;
+    if (st.flags == 0) return;
+    const int g = tid % G, r0 = tid / G;
+    const int cnt = st.cnt;
+    const bool have_act = USE_ACT && e.act != nullptr;
+#pragma unroll
+    for (int jj = 0; jj < CH; ++jj) {
+        const uint32_t f = (st.flags >> (4 * jj)) & 15u;
+        if (!(f & 1u)) continue;
+        const int rr = r0 + (j0 + jj) * RPI;
+        const int row = PAIRS ? 2 * rr : rr;
+        const float4 q0 = *(const float4*)(ct + row * LDC + 4 * g);
+        float v[4] = {q0.x, q0.y, q0.z, q0.w};
+        float w[4] = {0.f, 0.f, 0.f, 0.f};
+        if (PAIRS) { const float4 q1 = *(const float4*)(ct + (row + 1) * LDC + 4 * g); w[0] = q1.x; w[1] = q1.y; w[2] = q1.z; w[3] = q1.w; }
+        float am[4];
+        const uint32_t aw[4] = {st.act[jj].x, st.act[jj].y, st.act[jj].z, st.act[jj].w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            v[k] += bias4[k]; w[k] += bias4[k];
+            if (e.relu) { v[k] = fmaxf(v[k], 0.0f); w[k] = fmaxf(w[k], 0.0f); }
+            if (e.exp2) v[k] = exp2f(v[k]);
+            float a = 1.0f;
+            if (have_act) {
+                const float x = e.act_dtype == C1V_F32 ? __uint_as_float(aw[k]) : __uint_as_float((k & 1) ? (aw[k >> 1] & 0xFFFF0000u) : (aw[k >> 1] << 16));
+                a = x > 0.0f ? e.act_scale : 0.0f;
+            }
+            am[k] = a;
+        }
+        const uint32_t by = st.by[jj];
+        const int64_t d = st.di[jj];
+        if (MODE == C1V_ROW_STORE) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                v[k] *= am[k];
+                if (e.keep) v[k] = ((by >> (8 * k)) & 255u) ? v[k] * e.keep_scale : 0.0f;
+            }
+            epi_st<VW>(e, d, v, cnt);
+        } else if (MODE == C1V_ROW_UP2) {
+            epi_st<VW>(e, d, v, cnt);
+            if (f & 2u) epi_st<VW>(e, d + e.dst_cp, v, cnt);
+        } else if (MODE == C1V_ROW_UNPOOL) {
+            float hi[4], lo[4];                                  // row 2t and row 2t+1
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const bool s1 = ((by >> (8 * k)) & 255u) != 0;
+                const float x = v[k] * am[k];
+                hi[k] = s1 ? 0.0f : x; lo[k] = s1 ? x : 0.0f;
+            }
+            epi_st<VW>(e, d, hi, cnt);
+            epi_st<VW>(e, d + e.dst_cp, lo, cnt);
+        } else if (MODE == C1V_ROW_POOL2) {
+            uint32_t sb = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const bool s1 = w[k] > v[k];                    // first maximum wins ties
+                float x = s1 ? w[k] : v[k];
+                sb |= (s1 ? 1u : 0u) << (8 * k);
+                if (e.keep) x = ((by >> (8 * k)) & 255u) ? x * e.keep_scale : 0.0f;
+                v[k] = x;
+            }
+            if (e.sel) epi_st_bytes<VW>(e.sel + st.si[jj], sb, cnt);
+            epi_st<VW>(e, d, v, cnt);
+        } else {   // PAIRSUM
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = (((f & 2u) ? v[k] : 0.0f) + ((f & 4u) ? w[k] : 0.0f)) * am[k];
+            epi_st<VW>(e, d, v, cnt);
+        }
+    }
+}
+
+// all rows of the tile: chunk 0 was requested before the K loop (s0); further chunks (128-row tiles) ping-pong
+template <int BM, int BN, int MODE, int VW>
+__device__ __forceinline__ void epi_fast_rows(const EpiDev& e, const RowDiv& rd, EpiState& s0, const float* ct, int LDC, int m0, int n0, int tid,
+                                              const float bias4[4]) {
+    using S = EpiShape<BM, BN, MODE>;
+    if constexpr (S::ITEMS == S::CH) {
+        epi_finish<BM, BN, MODE, VW>(e, s0, ct, LDC, tid, 0, bias4);
+    } else {
+        EpiState s1;
+#pragma unroll 1
+        for (int j0 = 0; j0 < S::ITEMS; j0 += 2 * S::CH) {
+            epi_load<BM, BN, MODE, VW>(e, rd, s1, m0, n0, tid, j0 + S::CH);
+            epi_finish<BM, BN, MODE, VW>(e, s0, ct, LDC, tid, j0, bias4);
+            if (j0 + 2 * S::CH < S::ITEMS) epi_load<BM, BN, MODE, VW>(e, rd, s0, m0, n0, tid, j0 + 2 * S::CH);
+            epi_finish<BM, BN, MODE, VW>(e, s1, ct, LDC, tid, j0 + S::CH, bias4);
+        }
+    }
+}
+
+// wave-uniform dispatch over the row mode at a fixed vector width
+#define C1V_EPI_DISPATCH(VWV, CALL)                                                      \
+    switch (p.e.row_mode) {                                                              \
+        case C1V_ROW_STORE:   { constexpr int MODE_ = C1V_ROW_STORE;   constexpr int VW_ = VWV; CALL; } break; \
+        case C1V_ROW_POOL2:   { constexpr int MODE_ = C1V_ROW_POOL2;   constexpr int VW_ = VWV; CALL; } break; \
+        case C1V_ROW_UP2:     { constexpr int MODE_ = C1V_ROW_UP2;     constexpr int VW_ = VWV; CALL; } break; \
+        case C1V_ROW_PAIRSUM: { constexpr int MODE_ = C1V_ROW_PAIRSUM; constexpr int VW_ = VWV; CALL; } break; \
+        default:              { constexpr int MODE_ = C1V_ROW_UNPOOL;  constexpr int VW_ = VWV; CALL; } break; \
+    }
+
+#ifdef NT_STAMP
+// diagnostic build only: cycle stamps of wave 0 of every workgroup (start, after prologue, after K loop, end)
+__device__ unsigned long long nt_dbg[16 * 8192];
+extern "C" int c1v_debug_read_nt(unsigned long long* dst, int n) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(nt_dbg), sizeof(unsigned long long) * n);
+}
+#define NT_T(i) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp[i]) :: "memory"); \
+    __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define NT_T(i) do {} while (0)
+#endif
+
+template <typename T, int BM, int BN, int NS>
+__device__ __forceinline__ void nt_body(const NtParams& p, const int bx, const int by, const int wg_linear) {
+#ifdef NT_STAMP
+    unsigned long long stamp[16];
+#endif
+    NT_T(0);
+    constexpr int WTM = BM / 2, WTN = BN / 2, MI = WTM / 16, NJ = WTN / 16;
+    constexpr int A_IT = BM * 8 / 256, B_IT = BN * 8 / 256, LPT = A_IT + B_IT;
+    constexpr int STAGE = (BM + BN) * 128;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = bx * BM, n0 = by * BN;
+    const int lrow = tid >> 3, lpos = tid & 7;
+
+    // LDS-DMA: lane (lrow, lpos) of instruction i fills position lpos of tile row lrow + 32 i, which must hold logical
+    // chunk lpos ^ ((row>>1)&7) of that row (same 128-byte line, so coalescing is unchanged)
+    const char* ap[A_IT];
+    const char* bp[B_IT];
+    const RowDiv rd = make_rowdiv(m0, p.e.Le);
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+        const int row = lrow + i * 32;
+        int b, u;
+        rowdiv(rd, m0 + row < p.e.M ? row : p.e.M - 1 - m0, b, u);
+        ap[i] = p.A + (int64_t)b * p.a_bstride_b + (int64_t)(p.a_off + u) * p.lda_b + ((lpos ^ ((row >> 1) & 7)) << 4);
+    }
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+        const int row = lrow + i * 32;
+        int n = n0 + row;
+        if (n >= p.e.N) n = p.e.N - 1;
+        bp[i] = p.W + (int64_t)n * p.ldw_b + ((lpos ^ ((row >> 1) & 7)) << 4);
+    }
+    const int KT = (int)((p.Kb + 127) / 128);
+    NT_T(8);
+
+    auto issue = [&](int kt) {
+        char* sa = smem + (kt % NS) * STAGE + wave * 1024;
+        char* sb = sa + BM * 128;
+        const int64_t ko = (int64_t)kt * 128;
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) glds16(ap[i] + ko, sa + i * 4096);
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) glds16(bp[i] + ko, sb + i * 4096);
+    };
+
+    f32x4_t acc[MI][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s)
+        if (s < KT) issue(s);
+    NT_T(9);
+    // bias of this thread's epilogue channel group (see epilogue_rows): requested now, consumed after the K loop
+    float bias4[4] = {0.f, 0.f, 0.f, 0.f};
+    const int fastw = p.e.fastw;                       // wave-uniform: 4 / 2 = vectorised epilogue, 0 = element-wise
+    EpiState es;
+    {
+        const int nbias = n0 + 4 * (tid % (BN / 4));
+        if (p.e.bias) {
+            if (fastw == 4) {
+                if (nbias < p.e.N) { const float4 b = *(const float4*)(p.e.bias + nbias); bias4[0] = b.x; bias4[1] = b.y; bias4[2] = b.z; bias4[3] = b.w; }
+            } else if (fastw == 2) {
+                if (nbias < p.e.N) { const float2 b = *(const float2*)(p.e.bias + nbias); bias4[0] = b.x; bias4[1] = b.y; }
+                if (nbias + 2 < p.e.N) { const float2 b = *(const float2*)(p.e.bias + nbias + 2); bias4[2] = b.x; bias4[3] = b.y; }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) bias4[k] = nbias + k < p.e.N ? p.e.bias[nbias + k] : 0.0f;
+            }
+        }
+    }
+    NT_T(10);
+    // epilogue inputs of the first chunk of rows (older than every K tile but the first NS-1: the counted waits below
+    // stay valid because loads return in order -- they only wait a little longer at kt = 0)
+    if (fastw == 4) { C1V_EPI_DISPATCH(4, (epi_load<BM, BN, MODE_, VW_>(p.e, rd, es, m0, n0, tid, 0))) }
+    else if (fastw == 2) { C1V_EPI_DISPATCH(2, (epi_load<BM, BN, MODE_, VW_>(p.e, rd, es, m0, n0, tid, 0))) }
+    NT_T(1);
+
+    for (int kt = 0; kt < KT; ++kt) {
+        // tiles issued so far: min(KT, kt + NS - 1); all but the NS-2 youngest must have landed
+        if (kt + NS - 2 < KT) wait_vmcnt<(NS - 2) * LPT>(); else wait_vmcnt<0>();
+        block_barrier();
+        if (kt + NS - 1 < KT) issue(kt + NS - 1);
+        const char* sa = smem + (kt % NS) * STAGE;
+        const char* sb = sa + BM * 128;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            uint4 af[MI], bf[NJ];
+            const int ch = kk * 4 + (lane >> 4);
+#pragma unroll
+            for (int i = 0; i < MI; ++i) af[i] = *(const uint4*)(sa + lds_off(wm * WTM + i * 16 + (lane & 15), ch));
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) bf[j] = *(const uint4*)(sb + lds_off(wn * WTN + j * 16 + (lane & 15), ch));
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) mma16<T>(acc[i][j], af[i], bf[j]);
+        }
+    }
+
+    NT_T(2);
+    // Epilogue through LDS.  acc[i][j][r] is C[m0 + wm*WTM + i*16 + (lane>>4)*4 + r][n0 + wn*WTN + j*16 + (lane&15)]; the
+    // tile is parked in the (now dead) operand ring as fp32 and then walked by a ROLLED loop in which consecutive threads
+    // own consecutive 4-channel groups of a row.  Two reasons: (1) code size -- the per-element epilogue unrolled over
+    // the accumulator registers was ~40 KB of straight-line code executed once per wave, and its instruction-cache
+    // misses cost more than the K loop at this model's shapes (measured with s_memtime stamps: 10-19 k cycles);
+    // (2) stores and mask loads become whole 128-byte row segments instead of 32-byte scraps.
+    constexpr int LDC = BN + 4;
+    float* ct = (float*)smem;
+    __syncthreads();                                   // every wave is done reading the last operand stage
+    NT_T(4);
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                ct[(wm * WTM + i * 16 + (lane >> 4) * 4 + r) * LDC + wn * WTN + j * 16 + (lane & 15)] = acc[i][j][r];
+    __syncthreads();
+    NT_T(5);
+    if (fastw == 4) { C1V_EPI_DISPATCH(4, (epi_fast_rows<BM, BN, MODE_, VW_>(p.e, rd, es, ct, LDC, m0, n0, tid, bias4))) }
+    else if (fastw == 2) { C1V_EPI_DISPATCH(2, (epi_fast_rows<BM, BN, MODE_, VW_>(p.e, rd, es, ct, LDC, m0, n0, tid, bias4))) }
+    else {
+        switch (p.e.row_mode) {                        // wave-uniform; one specialised epilogue each
+            case C1V_ROW_STORE:   epilogue_rows<BM, BN, C1V_ROW_STORE>(p.e, ct, LDC, m0, n0, tid, bias4); break;
+            case C1V_ROW_POOL2:   epilogue_rows<BM, BN, C1V_ROW_POOL2>(p.e, ct, LDC, m0, n0, tid, bias4); break;
+            case C1V_ROW_UP2:     epilogue_rows<BM, BN, C1V_ROW_UP2>(p.e, ct, LDC, m0, n0, tid, bias4); break;
+            case C1V_ROW_PAIRSUM: epilogue_rows<BM, BN, C1V_ROW_PAIRSUM>(p.e, ct, LDC, m0, n0, tid, bias4); break;
+            default:              epilogue_rows<BM, BN, C1V_ROW_UNPOOL>(p.e, ct, LDC, m0, n0, tid, bias4); break;
+        }
+    }
+#ifdef NT_STAMP
+    NT_T(6);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    NT_T(3);
+    const int wg = wg_linear;
+    if (tid == 0 && wg < 8192) for (int i = 0; i < 12; ++i) nt_dbg[wg * 16 + i] = stamp[i];
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------------
+// TN kernel (wgrad): 128x128 output tile, K loop over rows r; operands are read "down the columns":
+//   bf16: ds_read_b64_tr_b16 (hardware transpose), fragment element 4w+q <-> row 16w + 4g + q of a 32-row step
+//   fp32: ds_read_b32 straight from the row-major tile (v_mfma_f32_16x16x4_f32 wants one k per lane group)
+// Row pitch = 128*esize + pad (bf16 +32 B, fp32 +64 B) keeps both read patterns conflict-free.  A tile image is
+// BR rows = 18 KiB, filled by 20 one-KiB LDS-DMA pieces (5 per wave; the last two land in a dead tail).
+// ------------------------------------------------------------------------------------------------------
+template <typename T> struct TnCfg;
+template <> struct TnCfg<bf16_raw> { static constexpr int BR = 64, PITCH = 128 * 2 + 32; };
+template <> struct TnCfg<float>    { static constexpr int BR = 32, PITCH = 128 * 4 + 64; };
+constexpr int TN_TILE = 20 * 1024;
+constexpr int TN_NS = 3;
+
+template <typename T>
+__device__ __forceinline__ void tn_body(const TnParams& p, const int bx, const int by, const int bz) {
+    using Cfg = TnCfg<T>;
+    constexpr int BR = Cfg::BR, PITCH = Cfg::PITCH;
+    constexpr int ES = sizeof(T);
+    constexpr int CPR = PITCH / 16, DCH = 128 * ES / 16;
+    constexpr int STAGE = 2 * TN_TILE;
+    constexpr int PPW = 5, LPT = 2 * PPW;
+    static_assert(BR * PITCH == 18 * 1024, "tile image is 18 KiB");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wi = wave >> 1, wj = wave & 1;
+    const int i0 = bx * 128, j0 = by * 128;
+    const int tap = bz / p.splits, split = bz - tap * p.splits;
+    const int64_t rb = p.r_begin + (int64_t)split * p.rows_per_split;
+    int64_t re = rb + p.rows_per_split;
+    if (re > p.r_end) re = p.r_end;
+    const int64_t nrows = re > rb ? re - rb : 0;
+    const int KT = (int)((nrows + BR - 1) / BR);
+
+    // per-lane LDS-DMA sources (byte offsets from the first row of a tile); padding lanes read the row's first chunk
+    int64_t aoff[PPW], doff[PPW];
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+        const int Lc = (wave + 4 * i) * 64 + lane;
+        int row = Lc / CPR;
+        int pos = Lc - row * CPR;
+        if (row >= BR) { row = 0; pos = 0; }
+        int pa = pos, pd = pos;
+        if (pos >= DCH || i0 * ES + pos * 16 >= p.Ia * ES) pa = 0;
+        if (pos >= DCH || j0 * ES + pos * 16 >= p.Ja * ES) pd = 0;
+        aoff[i] = (int64_t)row * p.lda_b + pa * 16;
+        doff[i] = (int64_t)row * p.ldd_b + pd * 16;
+    }
+    const char* abase = p.A + (rb + p.a_shift0 + tap) * p.lda_b + (int64_t)i0 * ES;
+    const char* dbase = p.D + rb * p.ldd_b + (int64_t)j0 * ES;
+
+    auto issue = [&](int kt) {
+        char* sa = smem + (kt % TN_NS) * STAGE + wave * 1024;
+        char* sd = sa + TN_TILE;
+        const char* at = abase + (int64_t)kt * BR * p.lda_b;
+        const char* dt = dbase + (int64_t)kt * BR * p.ldd_b;
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) glds16(at + aoff[i], sa + i * 4096);
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) glds16(dt + doff[i], sd + i * 4096);
+    };
+
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    f32x4_t accb[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) accb[j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    const bool do_bias = p.bias_out != nullptr && bx == 0 && tap == 0 && wi == 0;     // wave-uniform
+
+#pragma unroll
+    for (int s = 0; s < TN_NS - 1; ++s)
+        if (s < KT) issue(s);
+
+    for (int kt = 0; kt < KT; ++kt) {
+        if (kt + TN_NS - 2 < KT) wait_vmcnt<(TN_NS - 2) * LPT>(); else wait_vmcnt<0>();
+        block_barrier();
+        if (kt + TN_NS - 1 < KT) issue(kt + TN_NS - 1);
+        const char* sa = smem + (kt % TN_NS) * STAGE;
+        const char* sd = sa + TN_TILE;
+        if constexpr (sizeof(T) == 2) {
+            const int g = lane >> 4, q = (lane & 15) >> 2, pq = lane & 3;
+#pragma unroll
+            for (int ks = 0; ks < BR / 32; ++ks) {
+                uint4 af[4], df[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const char* a0 = sa + (ks * 32 + 4 * g + q) * PITCH + (wi * 64 + i * 16 + 4 * pq) * 2;
+                    s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(C1V_LDS_PTR(s16x4_t, a0));
+                    s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(C1V_LDS_PTR(s16x4_t, a0 + 16 * PITCH));
+                    af[i] = make_uint4(__builtin_bit_cast(uint2, lo).x, __builtin_bit_cast(uint2, lo).y,
+                                       __builtin_bit_cast(uint2, hi).x, __builtin_bit_cast(uint2, hi).y);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const char* d0 = sd + (ks * 32 + 4 * g + q) * PITCH + (wj * 64 + j * 16 + 4 * pq) * 2;
+                    s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(C1V_LDS_PTR(s16x4_t, d0));
+                    s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(C1V_LDS_PTR(s16x4_t, d0 + 16 * PITCH));
+                    df[j] = make_uint4(__builtin_bit_cast(uint2, lo).x, __builtin_bit_cast(uint2, lo).y,
+                                       __builtin_bit_cast(uint2, hi).x, __builtin_bit_cast(uint2, hi).y);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) mma16<bf16_raw>(acc[i][j], af[i], df[j]);
+                if (do_bias) {
+                    const uint4 ones = make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) mma16<bf16_raw>(accb[j], ones, df[j]);
+                }
+            }
+        } else {
+            for (int ks = 0; ks < BR / 4; ++ks) {
+                float af[4], df[4];
+                const int row = ks * 4 + (lane >> 4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) af[i] = *(const float*)(sa + row * PITCH + (wi * 64 + i * 16 + (lane & 15)) * 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) df[j] = *(const float*)(sd + row * PITCH + (wj * 64 + j * 16 + (lane & 15)) * 4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], df[j], acc[i][j], 0, 0, 0);
+                if (do_bias) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) accb[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, df[j], accb[j], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    const int tap_dst = p.flip ? (p.taps - 1 - tap) : tap;
+    float* out = p.out + (int64_t)split * p.slab_stride + (int64_t)tap_dst * p.tap_stride;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int ii = i0 + wi * 64 + i * 16 + (lane >> 4) * 4 + r;
+            if (ii >= p.I) continue;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int jj = j0 + wj * 64 + j * 16 + (lane & 15);
+                if (jj < p.J) out[(int64_t)ii * p.si + (int64_t)jj * p.sj] = acc[i][j][r];
+            }
+        }
+    }
+    if (do_bias && (lane >> 4) == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int jj = j0 + wj * 64 + j * 16 + (lane & 15);
+            if (jj < p.J) p.bias_out[(int64_t)split * p.bias_slab_stride + jj] = accb[j][0];
+        }
+    }
+}
+
+
+// LDS needs and tile choice, shared by the launchers of c1v_gemm.hip and c1v_gemm_pair.hip
+constexpr int TN_LDS = TN_NS * 2 * TN_TILE;
+enum NtVariant { NT_128 = 0, NT_64_DEEP = 1, NT_64 = 2 };
+static inline NtVariant nt_variant(const NtParams& p) {
+    const int64_t tiles128 = c1v_cdiv(p.e.M, 128) * c1v_cdiv(p.e.N, 128);
+    if (tiles128 >= 384) return NT_128;
+    // long K, few workgroups: latency-bound -- a deep ring (7 K tiles = 112 KiB in flight per CU) instead of occupancy
+    return c1v_cdiv(p.Kb, 128) >= 8 ? NT_64_DEEP : NT_64;
+}
+template <typename K> static void set_lds(K kern, int bytes) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}

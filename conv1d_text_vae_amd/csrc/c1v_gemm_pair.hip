@@ -1,0 +1,57 @@
+// One launch for the two GEMMs of a backward stage: the weight gradient (TN) and the data gradient (NT) both read the
+// stage's dO buffer and neither fills the chip at this model's shapes (tens to a few hundred workgroups each), so they
+// share one grid: workgroups [0, tn_blocks) run the wgrad tiles (the longer K loops, dispatched first), the rest the
+// dgrad tiles.  Measured before this (rocprofv3 kernel trace of the captured step): the two chains on two streams
+// overlapped little -- every cross-queue dependency of the graph cost 5-10 us.
+#include "c1v_gemm_dev.h"
+
+struct PairParams {
+    NtParams nt;
+    TnParams tn;
+    int tn_gi, tn_gij, tn_blocks, nt_gm;
+};
+
+template <typename T, int BM, int BN, int NS>
+__global__ __launch_bounds__(256) void gemm_pair_kernel(const PairParams pp) {
+    const int id = blockIdx.x;
+    if (id < pp.tn_blocks) {
+        const int bz = id / pp.tn_gij, r = id - bz * pp.tn_gij;
+        const int by = r / pp.tn_gi, bx = r - by * pp.tn_gi;
+        tn_body<T>(pp.tn, bx, by, bz);
+    } else {
+        const int r = id - pp.tn_blocks;
+        const int by = r / pp.nt_gm, bx = r - by * pp.nt_gm;
+        nt_body<T, BM, BN, NS>(pp.nt, bx, by, r);
+    }
+}
+
+template <typename T, int BM, int BN, int NS> static void launch_pair_v(PairParams& pp, hipStream_t st) {
+    constexpr int NT_LDS = NS * (BM + BN) * 128;
+    constexpr int LDS = NT_LDS > TN_LDS ? NT_LDS : TN_LDS;
+    static bool once = (set_lds(gemm_pair_kernel<T, BM, BN, NS>, LDS), true); (void)once;
+    pp.nt_gm = (int)c1v_cdiv(pp.nt.e.M, BM);
+    const int64_t nt_blocks = (int64_t)pp.nt_gm * c1v_cdiv(pp.nt.e.N, BN);
+    hipLaunchKernelGGL((gemm_pair_kernel<T, BM, BN, NS>), dim3((unsigned)(pp.tn_blocks + nt_blocks)), dim3(256), LDS, st, pp);
+}
+
+template <typename T> static int launch_pair_t(PairParams& pp, hipStream_t st) {
+    switch (nt_variant(pp.nt)) {
+        case NT_128:     launch_pair_v<T, 128, 128, 3>(pp, st); break;
+        case NT_64_DEEP: launch_pair_v<T, 64, 64, 8>(pp, st); break;
+        default:         launch_pair_v<T, 64, 64, 4>(pp, st); break;
+    }
+    C1V_LAUNCH_CHECK();
+    return 0;
+}
+
+int c1v_launch_pair(int dtype, const NtParams& nt, const TnParams& tn, hipStream_t st) {
+    if (c1v_check_nt(nt) || c1v_check_tn(tn)) return -1;
+    PairParams pp;
+    pp.nt = nt; pp.tn = tn;
+    pp.tn_gi = (int)c1v_cdiv(tn.I, 128);
+    pp.tn_gij = pp.tn_gi * (int)c1v_cdiv(tn.J, 128);
+    const int64_t tn_blocks = (int64_t)pp.tn_gij * tn.taps * tn.splits;
+    C1V_REQUIRE(tn_blocks < (1ll << 30), "pair launch: too many wgrad tiles");
+    pp.tn_blocks = (int)tn_blocks;
+    return dtype == C1V_F32 ? launch_pair_t<float>(pp, st) : launch_pair_t<bf16_raw>(pp, st);
+}

@@ -471,78 +471,91 @@ class VAEEngine:
             wt = slab(wname, sp, frozen)
             bt = slab(bname, sp, frozen)
             count = int(np.prod(self.seg_shapes[wname]))
-            ops = []
-            if not frozen:
-                ops.append(op('c1v_conv1d_wgrad', L.WgradArgs(X.t.data_ptr(), X.cp, C_in, dO.t.data_ptr(), dO.cp, F,
-                                                              self.code, k - 1, rows, -(k - 1), k, flip, tap_stride, si, sj,
-                                                              wt.data_ptr(), count, sp, bt.data_ptr(), F)))
-            return ops
+            if frozen:
+                return None
+            return ('c1v_conv1d_wgrad', L.WgradArgs(X.t.data_ptr(), X.cp, C_in, dO.t.data_ptr(), dO.cp, F,
+                                                    self.code, k - 1, rows, -(k - 1), k, flip, tap_stride, si, sj,
+                                                    wt.data_ptr(), count, sp, bt.data_ptr(), F))
 
         def dense_wgrad(a_ptr, lda, I, d_ptr, ldd, J, wname, bname, frozen=False):
             wt = slab(wname, 1, frozen)
             bt = slab(bname, 1, frozen)
-            ops = []
-            if not frozen:
-                ops.append(op('c1v_dense_wgrad', L.WgradArgs(a_ptr, lda, I, d_ptr, ldd, J, self.code, 0, B, 0, 1, 0, 0, J, 1,
-                                                             wt.data_ptr(), I * J, 1, bt.data_ptr(), J)))
-            return ops
+            if frozen:
+                return None
+            return ('c1v_dense_wgrad', L.WgradArgs(a_ptr, lda, I, d_ptr, ldd, J, self.code, 0, B, 0, 1, 0, 0, J, 1,
+                                                   wt.data_ptr(), I * J, 1, bt.data_ptr(), J))
 
-        # Backward as stages: in each stage the dgrad chain continues on the main stream while the wgrad of the same
-        # layer (it only needs the stage's dO buffer) runs on a side stream; the captured graph keeps both branches.
-        stages = []           # (main ops, side ops); side ops may start when the previous stage's main ops are done
+        # Backward as stages.  A stage = the data gradient of a layer (continues the chain) and the weight gradient of
+        # the same layer; both only need the stage's dO buffer.  Default: ONE launch per stage (c1v_bwd_pair, the two
+        # GEMMs share a grid).  C1V_BWD_PAIR=0 keeps the older form: dgrad chain on the main stream, wgrads on a side
+        # stream (the captured graph keeps both branches; every cross-queue edge of it costs 5-10 us).
+        stages = []           # (main ops, side ops, fused ops)
+
+        def stage(dgrad, wgrad, before=(), after=()):
+            """dgrad / wgrad: (entry point, args) or None; before / after: extra ops (side / main in the two-stream form)."""
+            main = ([op(*dgrad)] if dgrad else []) + list(after)
+            side = list(before) + ([op(*wgrad)] if wgrad else [])
+            if dgrad and wgrad:
+                is_dense = isinstance(dgrad[1], L.DenseArgs)
+                self._keep += [dgrad[1], wgrad[1]]
+                pa = L.BwdPairArgs(None if is_dense else C.pointer(dgrad[1]), C.pointer(dgrad[1]) if is_dense else None,
+                                   C.pointer(wgrad[1]))
+                fused = list(before) + [op('c1v_bwd_pair', pa)] + list(after)
+            else:
+                fused = side + main
+            stages.append((main, side, fused))
+
         C_last = g.dec_filters[-1]
-        side = [self.op_loss_reduce]
-        side += conv_wgrad(self.Xf, self.dOf, 'deconv_decoder_embeddings/kernel', 'deconv_decoder_embeddings/bias',
-                           C_last, self.V, 0, C_last * self.V, self.V, 1)
         e = self._epi(self.dOd[nd - 1].seq(), L.ROW_PAIRSUM, act=self.Xf.seq(), act_rowmul=2, act_scale=1.0)
-        main = [op('c1v_conv1d_dgrad', L.ConvArgs(self.dOf.seq(), g.pad_left, g.output_text_size, k,
-                                                  self.wop['out_dg'].data_ptr(), self.wld['out_dg'], C_last, e))]
-        stages.append((main, side))
+        stage(('c1v_conv1d_dgrad', L.ConvArgs(self.dOf.seq(), g.pad_left, g.output_text_size, k,
+                                              self.wop['out_dg'].data_ptr(), self.wld['out_dg'], C_last, e)),
+              conv_wgrad(self.Xf, self.dOf, 'deconv_decoder_embeddings/kernel', 'deconv_decoder_embeddings/bias',
+                         C_last, self.V, 0, C_last * self.V, self.V, 1),
+              before=[self.op_loss_reduce])
         for i in reversed(range(nd)):
             C_in = g.width if i == 0 else g.dec_filters[i - 1]
             F = g.dec_filters[i]
             nm = 'deconv_decoder_%d_deconv1d_part2' % (i + 1)
-            side = conv_wgrad(self.Xd[i], self.dOd[i], nm + '/kernel', nm + '/bias', C_in, F, 1, F * C_in, 1, C_in)
+            wg = conv_wgrad(self.Xd[i], self.dOd[i], nm + '/kernel', nm + '/bias', C_in, F, 1, F * C_in, 1, C_in)
             if i > 0:
                 e = self._epi(self.dOd[i - 1].seq(), L.ROW_PAIRSUM, act=self.Xd[i].seq(), act_rowmul=2, act_scale=1.0)
             else:
                 e = self._epi(self.dDense.seq(), L.ROW_STORE, act=self.Xd[0].seq(), act_rowmul=1, act_scale=1.0)
-            main = [op('c1v_deconv1d_dgrad', L.ConvArgs(self.dOd[i].seq(), k - 1, g.dec_in_len[i], k,
-                                                        self.wop['dec%d_dg' % i].data_ptr(), self.wld['dec%d_dg' % i], C_in, e))]
-            stages.append((main, side))
-        side = dense_wgrad(self.zd.data_ptr(), self.Dp, self.D, self.dDense.t.data_ptr(), self.nd_p, self.nd,
-                           'deconv_decoder_dense/kernel', 'deconv_decoder_dense/bias')
-        main = []
+            stage(('c1v_deconv1d_dgrad', L.ConvArgs(self.dOd[i].seq(), k - 1, g.dec_in_len[i], k,
+                                                    self.wop['dec%d_dg' % i].data_ptr(), self.wld['dec%d_dg' % i], C_in, e)), wg)
+        wg = dense_wgrad(self.zd.data_ptr(), self.Dp, self.D, self.dDense.t.data_ptr(), self.nd_p, self.nd,
+                         'deconv_decoder_dense/kernel', 'deconv_decoder_dense/bias')
         if not self.frozen:
             dzd_seq = L.Seq(self.dzd.data_ptr(), L.F32, B, self.D, 0, 1, self.D, self.D)
-            main.append(op('c1v_dense_dgrad', L.DenseArgs(self.dDense.t.data_ptr(), self.code, B, self.nd_p, self.nd_p,
-                                                          self.wop['dense_dg'].data_ptr(), self.wld['dense_dg'], self.D,
-                                                          self._epi(dzd_seq))))
-            main.append(op('c1v_latent_head_bwd', self._lat_train))
-        stages.append((main, side))
-        side = dense_wgrad(self.H.t.data_ptr(), self.flat_p, self.flat, self.dmlv.data_ptr(), self.D2p, 2 * self.D,
-                           'z_heads/kernel', 'z_heads/bias', self.frozen)
-        main = []
+            stage(('c1v_dense_dgrad', L.DenseArgs(self.dDense.t.data_ptr(), self.code, B, self.nd_p, self.nd_p,
+                                                  self.wop['dense_dg'].data_ptr(), self.wld['dense_dg'], self.D,
+                                                  self._epi(dzd_seq))), wg,
+                  after=[op('c1v_latent_head_bwd', self._lat_train)])
+        else:
+            stage(None, wg)
+        wg = dense_wgrad(self.H.t.data_ptr(), self.flat_p, self.flat, self.dmlv.data_ptr(), self.D2p, 2 * self.D,
+                         'z_heads/kernel', 'z_heads/bias', self.frozen)
+        dg = None
         if not self.frozen:
             F = g.n_filters[-1]
             e = self._epi(self.dOe[nl - 1].seq(), L.ROW_UNPOOL, reshape_w=F, act=self.H.seq(), act_scale=1.0 / KEEP_PROB,
                           sel=self.sel[nl - 1].data_ptr(), sel_bstride=g.enc_len_pool[nl - 1] * F, sel_cp=F)
-            main.append(op('c1v_dense_dgrad', L.DenseArgs(self.dmlv.data_ptr(), self.code, B, self.D2p, self.D2p,
-                                                          self.wop['heads_dg'].data_ptr(), self.wld['heads_dg'], self.flat, e)))
-        stages.append((main, side))
+            dg = ('c1v_dense_dgrad', L.DenseArgs(self.dmlv.data_ptr(), self.code, B, self.D2p, self.D2p,
+                                                 self.wop['heads_dg'].data_ptr(), self.wld['heads_dg'], self.flat, e))
+        stage(dg, wg)
         for l in reversed(range(nl)):
             C_in = g.input_vector_size if l == 0 else g.n_filters[l - 1]
             F = g.n_filters[l]
             nm = 'encoder_conv1d_%d' % (l + 1)
-            side = conv_wgrad(self.Xe[l], self.dOe[l], nm + '/kernel', nm + '/bias', C_in, F, 0, C_in * F, F, 1, self.frozen)
-            main = []
+            wg = conv_wgrad(self.Xe[l], self.dOe[l], nm + '/kernel', nm + '/bias', C_in, F, 0, C_in * F, F, 1, self.frozen)
+            dg = None
             if l > 0 and not self.frozen:
                 Fp = g.n_filters[l - 1]
                 e = self._epi(self.dOe[l - 1].seq(), L.ROW_UNPOOL, act=self.Xe[l].seq(), act_scale=1.0,
                               sel=self.sel[l - 1].data_ptr(), sel_bstride=g.enc_len_pool[l - 1] * Fp, sel_cp=Fp)
-                main.append(op('c1v_conv1d_dgrad', L.ConvArgs(self.dOe[l].seq(), 0, g.enc_in_len[l], k,
-                                                              self.wop['enc%d_dg' % l].data_ptr(), self.wld['enc%d_dg' % l], Fp, e)))
-            stages.append((main, side))
+                dg = ('c1v_conv1d_dgrad', L.ConvArgs(self.dOe[l].seq(), 0, g.enc_in_len[l], k,
+                                                     self.wop['enc%d_dg' % l].data_ptr(), self.wld['enc%d_dg' % l], Fp, e))
+            stage(dg, wg)
         self.bwd_stages = stages
         self.side_stream = torch.cuda.Stream(self.dev)
 
@@ -697,11 +710,15 @@ class VAEEngine:
             self.ids_in.copy_(torch.as_tensor(ids, dtype=torch.int32), non_blocking=True)
 
     def _run_backward(self, lo: int = 0, hi: Optional[int] = None):
-        """Stages [lo, hi) of backward: dgrad chain on the current stream, wgrads (and the loss scalars) on the side
-        stream; joined at the end."""
+        """Stages [lo, hi) of backward: one paired dgrad + wgrad launch per stage (default), or the dgrad chain on the
+        current stream with the wgrads (and the loss scalars) on the side stream, joined at the end."""
+        if os.environ.get('C1V_BWD_PAIR', '1') == '1':
+            for _, _, fused_ops in self.bwd_stages[lo:hi]:
+                self._run(fused_ops)
+            return
         main = torch.cuda.current_stream(self.dev)
         side = self.side_stream
-        for main_ops, side_ops in self.bwd_stages[lo:hi]:
+        for main_ops, side_ops, _ in self.bwd_stages[lo:hi]:
             if side_ops:
                 ev = torch.cuda.Event()
                 ev.record(main)

@@ -138,6 +138,18 @@ int c1v_conv1d_wgrad(const c1v_wgrad_args*, void* stream);
 int c1v_deconv1d_wgrad(const c1v_wgrad_args*, void* stream);
 int c1v_dense_wgrad(const c1v_wgrad_args*, void* stream);
 
+/* One backward stage in ONE launch: the data gradient (exactly one of conv_dgrad / dense_dgrad; conv_dgrad also
+ * serves the transposed conv) and the weight gradient of the same layer.  Both read the stage's output-gradient
+ * buffer and neither fills the chip alone, so their tiles share one grid; results are bit-identical to the two
+ * separate calls.  This is how the engine runs the backward of model_fn (reference :1283-1329, Keras' autodiff of
+ * the a1-a7 layers); the separate entry points above remain for callers that need one of the two. */
+typedef struct c1v_bwd_pair_args {
+    const c1v_conv1d_args* conv_dgrad;
+    const c1v_dense_args*  dense_dgrad;
+    const c1v_wgrad_args*  wgrad;
+} c1v_bwd_pair_args;
+int c1v_bwd_pair(const c1v_bwd_pair_args*, void* stream);
+
 /* column sums (bias gradients): out[s][c] = sum_{rows of split s} buf[row*ld + c], c < C */
 typedef struct c1v_colsum_args {
     const void* buf; int32_t dtype; int64_t rows; int64_t ld; int32_t C;

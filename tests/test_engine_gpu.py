@@ -105,6 +105,26 @@ def test_train_forward_backward_parity(name, dtype):
             assert rel_err(g[k_], ref) < 0.3, (k_, rel_err(g[k_], ref))
 
 
+@pytest.mark.parametrize('name', ['deep3', 'mid'])
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_paired_backward_launch_is_bit_identical(name, dtype, monkeypatch):
+    """c1v_bwd_pair (dgrad + wgrad tiles in one grid) against the two separate entry points: same kernels bodies, same
+    summation order, so the gradients must agree to the bit."""
+    c = CASES[name]
+    og, params, Wv, x, ids, eps, mask_e, mask_d = make_case(c)
+    got = {}
+    for mode in ('1', '0'):
+        monkeypatch.setenv('C1V_BWD_PAIR', mode)
+        eng = build_engine(c, og, params, Wv, dtype)
+        load_fixed(eng, x, ids, eps, mask_e, mask_d)
+        eng._run(eng.train_ops(False))
+        torch.cuda.synchronize()
+        got[mode] = (eng.get_grads(), eng.loss())
+    assert got['1'][1] == got['0'][1]
+    for k_, v in got['0'][0].items():
+        np.testing.assert_array_equal(got['1'][0][k_], v, err_msg=k_)
+
+
 @pytest.mark.parametrize('dtype', ['f32', 'bf16'])
 def test_nadam_trajectory_parity(dtype):
     """Five optimizer steps with fixed eps / masks: parameters and loss follow the oracle's Nadam(clipnorm=10)."""
