@@ -106,6 +106,11 @@ class SegDesc(C.Structure):
                 ('first_block', C.c_int32)]
 
 
+class LossReduceArgs(C.Structure):
+    _fields_ = [('xent_rows', C.c_void_p), ('ids', C.c_void_p), ('kl_b', C.c_void_p), ('B', C.c_int32), ('T', C.c_int32),
+                ('B_global', C.c_int32), ('out3', C.c_void_p), ('xent_b', C.c_void_p)]
+
+
 class NadamArgs(C.Structure):
     _fields_ = [('p', C.c_void_p), ('g', C.c_void_p), ('m', C.c_void_p), ('v', C.c_void_p), ('n', C.c_int64),
                 ('grad_scale', C.c_float),
@@ -160,6 +165,8 @@ SYMBOLS = {
     'c1v_loss_reduce': ([C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
                          C.c_void_p, C.c_void_p], C.c_int),
     'c1v_grad_finalize': ([C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p], C.c_int),
+    'c1v_grad_finalize_loss': ([C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, _P(LossReduceArgs), C.c_void_p],
+                               C.c_int),
     'c1v_sqnorm_partial': ([C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p], C.c_int),
     'c1v_nadam_step': ([_P(NadamArgs), C.c_void_p], C.c_int),
     'c1v_nadam_advance': ([C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p], C.c_int),

@@ -56,6 +56,23 @@ __device__ __forceinline__ void c1v_glds16(const void* gsrc, uint32_t lds_addr) 
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(a), "v"(gsrc) : "memory", "m0");
 }
 
+// Touch the 64-byte lines [1, LINES] of the kernel-argument segment with independent scalar loads and wait once: the
+// compiler fetches by-value argument structs lazily, one cold line (a trip to memory, ~1k cycles) at a time, wherever a
+// field is first used; after this every such fetch hits the scalar cache.  (HIP appends its hidden arguments to the
+// segment, so a touch up to 256 bytes past the explicit arguments is still inside it.)
+template <int LINES> __device__ __forceinline__ void c1v_touch_kernarg() {
+    static_assert(LINES >= 1 && LINES <= 7, "1..7 lines");
+    auto ka = __builtin_amdgcn_kernarg_segment_ptr();
+    uint32_t d0, d1, d2, d3, d4, d5, d6;
+    if constexpr (LINES <= 4)
+        asm volatile("s_load_dword %0, %4, 0x40\n\ts_load_dword %1, %4, 0x80\n\ts_load_dword %2, %4, 0xc0\n\ts_load_dword %3, %4, 0x100\n\t"
+                     "s_waitcnt lgkmcnt(0)" : "=&s"(d0), "=&s"(d1), "=&s"(d2), "=&s"(d3) : "s"(ka) : "memory");
+    else
+        asm volatile("s_load_dword %0, %7, 0x40\n\ts_load_dword %1, %7, 0x80\n\ts_load_dword %2, %7, 0xc0\n\ts_load_dword %3, %7, 0x100\n\t"
+                     "s_load_dword %4, %7, 0x140\n\ts_load_dword %5, %7, 0x180\n\ts_load_dword %6, %7, 0x1c0\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&s"(d0), "=&s"(d1), "=&s"(d2), "=&s"(d3), "=&s"(d4), "=&s"(d5), "=&s"(d6) : "s"(ka) : "memory");
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

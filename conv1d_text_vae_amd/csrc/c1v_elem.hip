@@ -2,6 +2,7 @@
 // Nadam + global-norm clip, EOS truncation, Philox RNG.  All are grid-stride, coalesced, and reduction orders are
 // fixed (no float atomics) so that two runs of a step are bit-identical.
 #include "c1v_common.h"
+#include "c1v_lossred.h"
 
 // ------------------------------------------------------------------------------------------------------
 // input packing
@@ -236,8 +237,14 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
     return r;
 }
 
+struct LossRedDev { const float* xent_rows; const int* ids; const float* kl_b; int B, T, B_global; float* out3; float* xent_b; };
+
 __global__ __launch_bounds__(256) void grad_finalize_kernel(const c1v_seg_desc* __restrict__ segs, int n_seg, float* __restrict__ grad,
-                                                            float* __restrict__ sq_partial) {
+                                                            float* __restrict__ sq_partial, int seg_blocks, LossRedDev lr) {
+    if ((int)blockIdx.x >= seg_blocks) {           // the extra block of c1v_grad_finalize_loss: the step's loss scalars
+        loss_reduce_body(lr.xent_rows, lr.ids, lr.kl_b, lr.B, lr.T, lr.B_global, lr.out3, lr.xent_b);
+        return;
+    }
     __shared__ float red[4];
     int si = 0;
     while (si + 1 < n_seg && (int)blockIdx.x >= segs[si + 1].first_block) ++si;
@@ -281,7 +288,19 @@ __global__ __launch_bounds__(256) void grad_finalize_kernel(const c1v_seg_desc* 
 
 extern "C" int c1v_grad_finalize(const c1v_seg_desc* segs, int32_t n_seg, int32_t total_blocks, float* grad, float* sq_partial, void* stream) {
     C1V_REQUIRE(segs && grad && n_seg > 0 && total_blocks > 0, "grad_finalize: bad argument");
-    hipLaunchKernelGGL(grad_finalize_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, segs, n_seg, grad, sq_partial);
+    hipLaunchKernelGGL(grad_finalize_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, segs, n_seg, grad, sq_partial,
+                       total_blocks, LossRedDev{});
+    C1V_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int c1v_grad_finalize_loss(const c1v_seg_desc* segs, int32_t n_seg, int32_t total_blocks, float* grad, float* sq_partial,
+                                      const c1v_loss_reduce_args* l, void* stream) {
+    C1V_REQUIRE(segs && grad && n_seg > 0 && total_blocks > 0, "grad_finalize_loss: bad argument");
+    C1V_REQUIRE(l && l->xent_rows && l->ids && l->out3 && l->B > 0 && l->T > 0 && l->B_global > 0, "grad_finalize_loss: bad loss argument");
+    const LossRedDev lr{l->xent_rows, l->ids, l->kl_b, l->B, l->T, l->B_global, l->out3, l->xent_b};
+    hipLaunchKernelGGL(grad_finalize_kernel, dim3((unsigned)total_blocks + 1), dim3(256), 0, (hipStream_t)stream, segs, n_seg, grad, sq_partial,
+                       total_blocks, lr);
     C1V_LAUNCH_CHECK();
     return 0;
 }

@@ -4,6 +4,8 @@
 
 template <typename T, int BM, int BN, int NS>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(const NtParams p) {
+    static_assert(sizeof(NtParams) + 192 > 0x100, "kernarg lines touched below");
+    c1v_touch_kernarg<4>();
     nt_body<T, BM, BN, NS>(p, blockIdx.x, blockIdx.y, blockIdx.x + gridDim.x * blockIdx.y);
 }
 template <typename T>

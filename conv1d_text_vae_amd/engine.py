@@ -510,8 +510,7 @@ class VAEEngine:
         stage(('c1v_conv1d_dgrad', L.ConvArgs(self.dOf.seq(), g.pad_left, g.output_text_size, k,
                                               self.wop['out_dg'].data_ptr(), self.wld['out_dg'], C_last, e)),
               conv_wgrad(self.Xf, self.dOf, 'deconv_decoder_embeddings/kernel', 'deconv_decoder_embeddings/bias',
-                         C_last, self.V, 0, C_last * self.V, self.V, 1),
-              before=[self.op_loss_reduce])
+                         C_last, self.V, 0, C_last * self.V, self.V, 1))
         for i in reversed(range(nd)):
             C_in = g.width if i == 0 else g.dec_filters[i - 1]
             F = g.dec_filters[i]
@@ -579,22 +578,33 @@ class VAEEngine:
         bucketed = self.world > 1 or self.force_bucketed
         n_partial = 256 if bucketed else self.fin_blocks
 
-        def make_finalize(table, with_sq):
+        f_fin_loss = self.lib.c1v_grad_finalize_loss
+        loss_args = L.LossReduceArgs(self.xent_rows.data_ptr(), self.ids_in.data_ptr(), self.kl_b.data_ptr(), B,
+                                     g.output_text_size, self.Bg, self.loss_out.data_ptr(), self.xent_b.data_ptr())
+        self._keep.append(loss_args)
+
+        def make_finalize(table, with_sq, with_loss):
+            """Sum the wgrad slabs of the table's segments into the flat gradient; with_loss: the step's loss scalars
+            ride along as one extra workgroup of the same launch."""
             descs, n, blocks = table
             self._keep.append(descs)
 
             def fin():
-                L.check(f_fin(descs.data_ptr(), n, blocks, self.grads.data_ptr(),
-                              self.sq_partial.data_ptr() if with_sq else None, self._stream()), 'c1v_grad_finalize')
+                sq = self.sq_partial.data_ptr() if with_sq else None
+                if with_loss:
+                    L.check(f_fin_loss(descs.data_ptr(), n, blocks, self.grads.data_ptr(), sq, C.byref(loss_args),
+                                       self._stream()), 'c1v_grad_finalize_loss')
+                else:
+                    L.check(f_fin(descs.data_ptr(), n, blocks, self.grads.data_ptr(), sq, self._stream()), 'c1v_grad_finalize')
             return fin
 
-        finalize = make_finalize((self.seg_descs, self.n_seg, self.fin_blocks), True)
+        finalize = make_finalize((self.seg_descs, self.n_seg, self.fin_blocks), True, True)
         # data-parallel buckets (reverse layer order, SURVEY 8d): the decoder-side gradients are complete after the
         # first `n_dec_stages` backward stages and can be summed over the ranks while the rest of backward runs.  The
         # flat buffer keeps the segments in layer order, so each bucket is one contiguous range of `grads`.
         is_enc = lambda n: n.startswith('encoder_conv1d_') or n.startswith('z_heads')
-        self.ops_finalize_dec = [make_finalize(seg_table(lambda n: not is_enc(n)), False)]
-        self.ops_finalize_enc = [make_finalize(seg_table(is_enc), False)]
+        self.ops_finalize_dec = [make_finalize(seg_table(lambda n: not is_enc(n)), False, True)]
+        self.ops_finalize_enc = [make_finalize(seg_table(is_enc), False, False)]
         self.n_dec_stages = nd + 2
         self.enc_range = (0, self.seg_off['deconv_decoder_dense/kernel'])
         self.dec_range = (self.seg_off['deconv_decoder_dense/kernel'], self.P)

@@ -259,6 +259,13 @@ int c1v_loss_reduce(const float* xent_rows, const int32_t* ids, const float* kl_
 typedef struct c1v_seg_desc { const float* slab; int64_t slab_stride; int32_t splits; int32_t reps; int64_t rep_stride; int64_t offset; int64_t count; int32_t frozen; int32_t first_block; } c1v_seg_desc;
 /* segment i owns blocks [first_block_i, first_block_{i+1}) (ceil(count / C1V_CHUNK) each); sq_partial has total_blocks entries */
 int c1v_grad_finalize(const c1v_seg_desc* segs /*device*/, int32_t n_seg, int32_t total_blocks, float* grad, float* sq_partial, void* stream);
+/* c1v_grad_finalize plus the step's loss scalars (c1v_loss_reduce, same arithmetic and order) in one extra workgroup of
+ * the same launch: both close the backward pass and the scalars are off the critical path. */
+typedef struct c1v_loss_reduce_args {
+    const float* xent_rows; const int32_t* ids; const float* kl_b; int32_t B, T, B_global; float* out3; float* xent_b;
+} c1v_loss_reduce_args;
+int c1v_grad_finalize_loss(const c1v_seg_desc* segs /*device*/, int32_t n_seg, int32_t total_blocks, float* grad, float* sq_partial,
+                           const c1v_loss_reduce_args* loss, void* stream);
 int c1v_sqnorm_partial(const float* x, int64_t n, float* sq_partial, int32_t n_partial, void* stream);
 typedef struct c1v_nadam_args {
     float* p; const float* g; float* m; float* v; int64_t n;
