@@ -3,13 +3,13 @@
 #include <stdlib.h>
 
 template <typename T, int BM, int BN, int NS>
-__global__ __launch_bounds__(256) void gemm_nt_kernel(const NtParams p) {
+__global__ __launch_bounds__(C1V_GEMM_THREADS) void gemm_nt_kernel(const NtParams p) {
     static_assert(sizeof(NtParams) + 192 > 0x100, "kernarg lines touched below");
     c1v_touch_kernarg<4>();
     nt_body<T, BM, BN, NS>(p, blockIdx.x, blockIdx.y, blockIdx.x + gridDim.x * blockIdx.y);
 }
 template <typename T>
-__global__ __launch_bounds__(256) void gemm_tn_kernel(const TnParams p) {
+__global__ __launch_bounds__(C1V_GEMM_THREADS) void gemm_tn_kernel(const TnParams p) {
     tn_body<T>(p, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
@@ -20,7 +20,7 @@ template <typename T, int BM, int BN, int NS> static void launch_nt_v(const NtPa
     constexpr int LDS = NS * (BM + BN) * 128;
     static bool once = (set_lds(gemm_nt_kernel<T, BM, BN, NS>, LDS), true); (void)once;
     dim3 grid((unsigned)c1v_cdiv(p.e.M, BM), (unsigned)c1v_cdiv(p.e.N, BN));
-    hipLaunchKernelGGL((gemm_nt_kernel<T, BM, BN, NS>), grid, dim3(256), LDS, st, p);
+    hipLaunchKernelGGL((gemm_nt_kernel<T, BM, BN, NS>), grid, dim3(C1V_GEMM_THREADS), LDS, st, p);
 }
 
 template <typename T> static int launch_nt_t(const NtParams& p, hipStream_t st) {
@@ -59,7 +59,7 @@ int c1v_launch_nt(int dtype, const NtParams& p, hipStream_t st) {
 template <typename T> static int launch_tn_t(const TnParams& p, hipStream_t st) {
     static bool once = (set_lds(gemm_tn_kernel<T>, TN_LDS), true); (void)once;
     dim3 grid((unsigned)c1v_cdiv(p.I, 128), (unsigned)c1v_cdiv(p.J, 128), (unsigned)(p.taps * p.splits));
-    hipLaunchKernelGGL((gemm_tn_kernel<T>), grid, dim3(256), TN_LDS, st, p);
+    hipLaunchKernelGGL((gemm_tn_kernel<T>), grid, dim3(C1V_GEMM_THREADS), TN_LDS, st, p);
     C1V_LAUNCH_CHECK();
     return 0;
 }

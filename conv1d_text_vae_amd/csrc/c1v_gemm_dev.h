@@ -431,9 +431,19 @@ extern "C" int c1v_debug_read_nt(unsigned long long* dst, int n) {
 }
 #define NT_T(i) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp[i]) :: "memory"); \
     __builtin_amdgcn_sched_barrier(0); } while (0)
+#define NT_TICK(i) do { unsigned long long now_; __builtin_amdgcn_sched_barrier(0); \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_) :: "memory"); __builtin_amdgcn_sched_barrier(0); \
+    tacc[i] += now_ - tlast; tlast = now_; } while (0)
 #else
 #define NT_T(i) do {} while (0)
+#define NT_TICK(i) do {} while (0)
 #endif
+
+// Workgroup = 6 waves: waves 0-3 compute (2x2 over the tile), waves 4 and 5 only feed the LDS ring (wave 4 the A rows,
+// wave 5 the W rows).  Measured with per-phase s_memtime stamps when all four waves did both jobs: the LDS-DMA requests
+// of one 16 KiB K tile take ~270 cycles to ISSUE (the CU accepts 64 B/clk) and block the issuing wave meanwhile, serially
+// with its ~170 cycles of fragment reads and ~200 of MFMA -- 580 cycles per tile against 256 for the data alone.
+constexpr int C1V_GEMM_THREADS = 384;
 
 template <typename T, int BM, int BN, int NS>
 __device__ __forceinline__ void nt_body(const NtParams& p, const int bx, const int by, const int wg_linear) {
@@ -441,48 +451,62 @@ __device__ __forceinline__ void nt_body(const NtParams& p, const int bx, const i
     unsigned long long stamp[16];
 #endif
     NT_T(0);
+    static_assert(BM == BN, "one feeder wave per operand: equal request counts");
     constexpr int WTM = BM / 2, WTN = BN / 2, MI = WTM / 16, NJ = WTN / 16;
-    constexpr int A_IT = BM * 8 / 256, B_IT = BN * 8 / 256, LPT = A_IT + B_IT;
+    constexpr int IPT = BM / 8;                        // LDS-DMA requests per K tile per feeder wave (8 rows each)
     constexpr int STAGE = (BM + BN) * 128;
+    static_assert((NS - 2) * IPT <= 63, "vmcnt is a 6-bit counter");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = (wave >> 1) & 1, wn = wave & 1;
     const int m0 = bx * BM, n0 = by * BN;
-    const int lrow = tid >> 3, lpos = tid & 7;
-
-    // LDS-DMA: lane (lrow, lpos) of instruction i fills position lpos of tile row lrow + 32 i, which must hold logical
-    // chunk lpos ^ ((row>>1)&7) of that row (same 128-byte line, so coalescing is unchanged)
-    const char* ap[A_IT];
-    const char* bp[B_IT];
     const RowDiv rd = make_rowdiv(m0, p.e.Le);
-#pragma unroll
-    for (int i = 0; i < A_IT; ++i) {
-        const int row = lrow + i * 32;
-        int b, u;
-        rowdiv(rd, m0 + row < p.e.M ? row : p.e.M - 1 - m0, b, u);
-        ap[i] = p.A + (int64_t)b * p.a_bstride_b + (int64_t)(p.a_off + u) * p.lda_b + ((lpos ^ ((row >> 1) & 7)) << 4);
-    }
-#pragma unroll
-    for (int i = 0; i < B_IT; ++i) {
-        const int row = lrow + i * 32;
-        int n = n0 + row;
-        if (n >= p.e.N) n = p.e.N - 1;
-        bp[i] = p.W + (int64_t)n * p.ldw_b + ((lpos ^ ((row >> 1) & 7)) << 4);
-    }
     const int KT = (int)((p.Kb + 127) / 128);
-    NT_T(8);
 
-    auto issue = [&](int kt) {
-        char* sa = smem + (kt % NS) * STAGE + wave * 1024;
-        char* sb = sa + BM * 128;
-        const int64_t ko = (int64_t)kt * 128;
+    if (wave >= 4) {
+        // ---- feeder: lane (prow, ppos) of request i fills position ppos of tile row 8 i + prow, which must hold logical
+        // chunk ppos ^ ((row>>1)&7) of that row (same 128-byte line, so coalescing is unchanged)
+        const int prow = lane >> 3, ppos = lane & 7;
+        const char* src[IPT];
+        if (wave == 4) {
 #pragma unroll
-        for (int i = 0; i < A_IT; ++i) glds16(ap[i] + ko, sa + i * 4096);
+            for (int i = 0; i < IPT; ++i) {
+                const int row = 8 * i + prow;
+                int b, u;
+                rowdiv(rd, m0 + row < p.e.M ? row : p.e.M - 1 - m0, b, u);
+                src[i] = p.A + (int64_t)b * p.a_bstride_b + (int64_t)(p.a_off + u) * p.lda_b + ((ppos ^ ((row >> 1) & 7)) << 4);
+            }
+        } else {
 #pragma unroll
-        for (int i = 0; i < B_IT; ++i) glds16(bp[i] + ko, sb + i * 4096);
-    };
+            for (int i = 0; i < IPT; ++i) {
+                const int row = 8 * i + prow;
+                int n = n0 + row;
+                if (n >= p.e.N) n = p.e.N - 1;
+                src[i] = p.W + (int64_t)n * p.ldw_b + ((ppos ^ ((row >> 1) & 7)) << 4);
+            }
+        }
+        const int dst0 = wave == 4 ? 0 : BM * 128;
+        auto issue = [&](int kt) {
+            char* d = smem + (kt % NS) * STAGE + dst0;
+            const int64_t ko = (int64_t)kt * 128;
+#pragma unroll
+            for (int i = 0; i < IPT; ++i) glds16(src[i] + ko, d + i * 1024);
+        };
+#pragma unroll
+        for (int s = 0; s < NS - 1; ++s)
+            if (s < KT) issue(s);
+        for (int kt = 0; kt < KT; ++kt) {
+            // tiles requested so far: min(KT, kt + NS - 1); all but the NS-2 youngest must have landed
+            if (kt + NS - 2 < KT) wait_vmcnt<(NS - 2) * IPT>(); else wait_vmcnt<0>();
+            block_barrier();                           // tile kt is in LDS; stage (kt-1) % NS is free again
+            if (kt + NS - 1 < KT) issue(kt + NS - 1);
+        }
+        block_barrier();                               // the two barriers of the epilogue below
+        block_barrier();
+        return;
+    }
 
     f32x4_t acc[MI][NJ];
 #pragma unroll
@@ -490,10 +514,6 @@ __device__ __forceinline__ void nt_body(const NtParams& p, const int bx, const i
 #pragma unroll
         for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-#pragma unroll
-    for (int s = 0; s < NS - 1; ++s)
-        if (s < KT) issue(s);
-    NT_T(9);
     // bias of this thread's epilogue channel group (see epilogue_rows): requested now, consumed after the K loop
     float bias4[4] = {0.f, 0.f, 0.f, 0.f};
     const int fastw = p.e.fastw;                       // wave-uniform: 4 / 2 = vectorised epilogue, 0 = element-wise
@@ -512,18 +532,13 @@ __device__ __forceinline__ void nt_body(const NtParams& p, const int bx, const i
             }
         }
     }
-    NT_T(10);
-    // epilogue inputs of the first chunk of rows (older than every K tile but the first NS-1: the counted waits below
-    // stay valid because loads return in order -- they only wait a little longer at kt = 0)
+    // epilogue inputs of the first chunk of rows: requested while the feeders fill the ring
     if (fastw == 4) { C1V_EPI_DISPATCH(4, (epi_load<BM, BN, MODE_, VW_>(p.e, rd, es, m0, n0, tid, 0))) }
     else if (fastw == 2) { C1V_EPI_DISPATCH(2, (epi_load<BM, BN, MODE_, VW_>(p.e, rd, es, m0, n0, tid, 0))) }
     NT_T(1);
 
     for (int kt = 0; kt < KT; ++kt) {
-        // tiles issued so far: min(KT, kt + NS - 1); all but the NS-2 youngest must have landed
-        if (kt + NS - 2 < KT) wait_vmcnt<(NS - 2) * LPT>(); else wait_vmcnt<0>();
         block_barrier();
-        if (kt + NS - 1 < KT) issue(kt + NS - 1);
         const char* sa = smem + (kt % NS) * STAGE;
         const char* sb = sa + BM * 128;
 #pragma unroll
@@ -577,7 +592,7 @@ __device__ __forceinline__ void nt_body(const NtParams& p, const int bx, const i
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     NT_T(3);
     const int wg = wg_linear;
-    if (tid == 0 && wg < 8192) for (int i = 0; i < 12; ++i) nt_dbg[wg * 16 + i] = stamp[i];
+    if (tid == 0 && wg < 8192) for (int i = 0; i < 8; ++i) nt_dbg[wg * 16 + i] = stamp[i];
 #endif
 }
 
@@ -586,7 +601,7 @@ __device__ __forceinline__ void nt_body(const NtParams& p, const int bx, const i
 //   bf16: ds_read_b64_tr_b16 (hardware transpose), fragment element 4w+q <-> row 16w + 4g + q of a 32-row step
 //   fp32: ds_read_b32 straight from the row-major tile (v_mfma_f32_16x16x4_f32 wants one k per lane group)
 // Row pitch = 128*esize + pad (bf16 +32 B, fp32 +64 B) keeps both read patterns conflict-free.  A tile image is
-// BR rows = 18 KiB, filled by 20 one-KiB LDS-DMA pieces (5 per wave; the last two land in a dead tail).
+// BR rows = 18 KiB, filled by 18 one-KiB LDS-DMA requests of that operand's feeder wave (waves 4 / 5, see nt_body).
 // ------------------------------------------------------------------------------------------------------
 template <typename T> struct TnCfg;
 template <> struct TnCfg<bf16_raw> { static constexpr int BR = 64, PITCH = 128 * 2 + 32; };
@@ -601,8 +616,9 @@ __device__ __forceinline__ void tn_body(const TnParams& p, const int bx, const i
     constexpr int ES = sizeof(T);
     constexpr int CPR = PITCH / 16, DCH = 128 * ES / 16;
     constexpr int STAGE = 2 * TN_TILE;
-    constexpr int PPW = 5, LPT = 2 * PPW;
-    static_assert(BR * PITCH == 18 * 1024, "tile image is 18 KiB");
+    constexpr int NPIECE = BR * PITCH / 1024;         // LDS-DMA requests (1 KiB each) per tile image
+    static_assert(BR * PITCH == 18 * 1024 && NPIECE * 64 == BR * CPR, "tile image is 18 KiB of whole requests");
+    static_assert((TN_NS - 2) * NPIECE <= 63, "vmcnt is a 6-bit counter");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -616,33 +632,42 @@ __device__ __forceinline__ void tn_body(const TnParams& p, const int bx, const i
     const int64_t nrows = re > rb ? re - rb : 0;
     const int KT = (int)((nrows + BR - 1) / BR);
 
-    // per-lane LDS-DMA sources (byte offsets from the first row of a tile); padding lanes read the row's first chunk
-    int64_t aoff[PPW], doff[PPW];
-#pragma unroll
-    for (int i = 0; i < PPW; ++i) {
-        const int Lc = (wave + 4 * i) * 64 + lane;
-        int row = Lc / CPR;
-        int pos = Lc - row * CPR;
-        if (row >= BR) { row = 0; pos = 0; }
-        int pa = pos, pd = pos;
-        if (pos >= DCH || i0 * ES + pos * 16 >= p.Ia * ES) pa = 0;
-        if (pos >= DCH || j0 * ES + pos * 16 >= p.Ja * ES) pd = 0;
-        aoff[i] = (int64_t)row * p.lda_b + pa * 16;
-        doff[i] = (int64_t)row * p.ldd_b + pd * 16;
-    }
     const char* abase = p.A + (rb + p.a_shift0 + tap) * p.lda_b + (int64_t)i0 * ES;
     const char* dbase = p.D + rb * p.ldd_b + (int64_t)j0 * ES;
 
-    auto issue = [&](int kt) {
-        char* sa = smem + (kt % TN_NS) * STAGE + wave * 1024;
-        char* sd = sa + TN_TILE;
-        const char* at = abase + (int64_t)kt * BR * p.lda_b;
-        const char* dt = dbase + (int64_t)kt * BR * p.ldd_b;
+    if (wave >= 4) {
+        // ---- feeder (wave 4: A image, wave 5: D image): per-lane sources as byte offsets from the first row of a tile;
+        // lanes that land in the row padding read the row's first chunk
+        const bool feed_a = wave == 4;
+        const int64_t ld_b = feed_a ? p.lda_b : p.ldd_b;
+        const int col0_b = (feed_a ? i0 : j0) * ES, cols_b = (feed_a ? p.Ia : p.Ja) * ES;
+        int64_t off[NPIECE];
 #pragma unroll
-        for (int i = 0; i < PPW; ++i) glds16(at + aoff[i], sa + i * 4096);
+        for (int i = 0; i < NPIECE; ++i) {
+            const int Lc = i * 64 + lane;
+            const int row = Lc / CPR;
+            int pos = Lc - row * CPR;
+            if (pos >= DCH || col0_b + pos * 16 >= cols_b) pos = 0;
+            off[i] = (int64_t)row * ld_b + pos * 16;
+        }
+        const char* base = feed_a ? abase : dbase;
+        const int dst0 = feed_a ? 0 : TN_TILE;
+        auto issue = [&](int kt) {
+            char* d = smem + (kt % TN_NS) * STAGE + dst0;
+            const char* t = base + (int64_t)kt * BR * ld_b;
 #pragma unroll
-        for (int i = 0; i < PPW; ++i) glds16(dt + doff[i], sd + i * 4096);
-    };
+            for (int i = 0; i < NPIECE; ++i) glds16(t + off[i], d + i * 1024);
+        };
+#pragma unroll
+        for (int s = 0; s < TN_NS - 1; ++s)
+            if (s < KT) issue(s);
+        for (int kt = 0; kt < KT; ++kt) {
+            if (kt + TN_NS - 2 < KT) wait_vmcnt<(TN_NS - 2) * NPIECE>(); else wait_vmcnt<0>();
+            block_barrier();
+            if (kt + TN_NS - 1 < KT) issue(kt + TN_NS - 1);
+        }
+        return;
+    }
 
     f32x4_t acc[4][4];
 #pragma unroll
@@ -654,14 +679,8 @@ __device__ __forceinline__ void tn_body(const TnParams& p, const int bx, const i
     for (int j = 0; j < 4; ++j) accb[j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     const bool do_bias = p.bias_out != nullptr && bx == 0 && tap == 0 && wi == 0;     // wave-uniform
 
-#pragma unroll
-    for (int s = 0; s < TN_NS - 1; ++s)
-        if (s < KT) issue(s);
-
     for (int kt = 0; kt < KT; ++kt) {
-        if (kt + TN_NS - 2 < KT) wait_vmcnt<(TN_NS - 2) * LPT>(); else wait_vmcnt<0>();
         block_barrier();
-        if (kt + TN_NS - 1 < KT) issue(kt + TN_NS - 1);
         const char* sa = smem + (kt % TN_NS) * STAGE;
         const char* sd = sa + TN_TILE;
         if constexpr (sizeof(T) == 2) {

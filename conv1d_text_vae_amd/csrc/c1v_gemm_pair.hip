@@ -12,7 +12,7 @@ struct PairParams {
 };
 
 template <typename T, int BM, int BN, int NS>
-__global__ __launch_bounds__(256) void gemm_pair_kernel(const PairParams pp) {
+__global__ __launch_bounds__(C1V_GEMM_THREADS) void gemm_pair_kernel(const PairParams pp) {
     static_assert(sizeof(PairParams) + 192 > 0x1c0, "kernarg lines touched below");
     c1v_touch_kernarg<7>();
     const int id = blockIdx.x;
@@ -33,7 +33,7 @@ template <typename T, int BM, int BN, int NS> static void launch_pair_v(PairPara
     static bool once = (set_lds(gemm_pair_kernel<T, BM, BN, NS>, LDS), true); (void)once;
     pp.nt_gm = (int)c1v_cdiv(pp.nt.e.M, BM);
     const int64_t nt_blocks = (int64_t)pp.nt_gm * c1v_cdiv(pp.nt.e.N, BN);
-    hipLaunchKernelGGL((gemm_pair_kernel<T, BM, BN, NS>), dim3((unsigned)(pp.tn_blocks + nt_blocks)), dim3(256), LDS, st, pp);
+    hipLaunchKernelGGL((gemm_pair_kernel<T, BM, BN, NS>), dim3((unsigned)(pp.tn_blocks + nt_blocks)), dim3(C1V_GEMM_THREADS), LDS, st, pp);
 }
 
 template <typename T> static int launch_pair_t(PairParams& pp, hipStream_t st) {
