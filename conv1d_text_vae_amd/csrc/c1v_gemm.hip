@@ -26,7 +26,6 @@ template <typename T, int BM, int BN, int NS> static void launch_nt_v(const NtPa
 template <typename T> static int launch_nt_t(const NtParams& p, hipStream_t st) {
     switch (nt_variant(p)) {
         case NT_128:     launch_nt_v<T, 128, 128, 3>(p, st); break;
-        case NT_64_DEEP: launch_nt_v<T, 64, 64, 8>(p, st); break;
         default:         launch_nt_v<T, 64, 64, 4>(p, st); break;
     }
     C1V_LAUNCH_CHECK();

@@ -606,8 +606,8 @@ __device__ __forceinline__ void nt_body(const NtParams& p, const int bx, const i
 template <typename T> struct TnCfg;
 template <> struct TnCfg<bf16_raw> { static constexpr int BR = 64, PITCH = 128 * 2 + 32; };
 template <> struct TnCfg<float>    { static constexpr int BR = 32, PITCH = 128 * 4 + 64; };
-constexpr int TN_TILE = 20 * 1024;
-constexpr int TN_NS = 3;
+constexpr int TN_TILE = 18 * 1024;
+constexpr int TN_NS = 2;
 
 template <typename T>
 __device__ __forceinline__ void tn_body(const TnParams& p, const int bx, const int by, const int bz) {
@@ -762,12 +762,13 @@ __device__ __forceinline__ void tn_body(const TnParams& p, const int bx, const i
 
 // LDS needs and tile choice, shared by the launchers of c1v_gemm.hip and c1v_gemm_pair.hip
 constexpr int TN_LDS = TN_NS * 2 * TN_TILE;
-enum NtVariant { NT_128 = 0, NT_64_DEEP = 1, NT_64 = 2 };
+enum NtVariant { NT_128 = 0, NT_64 = 2 };
 static inline NtVariant nt_variant(const NtParams& p) {
+    // Measured (s_memtime stamps, compute removed): a CU takes in ~30 B/clk whatever the depth of the ring, so the K loops
+    // of these small GEMMs are bound by the bytes ONE workgroup needs; shallow rings that let two workgroups share a CU
+    // (and a wgrad + dgrad pair share the chip) beat deep ones.
     const int64_t tiles128 = c1v_cdiv(p.e.M, 128) * c1v_cdiv(p.e.N, 128);
-    if (tiles128 >= 384) return NT_128;
-    // long K, few workgroups: latency-bound -- a deep ring (7 K tiles = 112 KiB in flight per CU) instead of occupancy
-    return c1v_cdiv(p.Kb, 128) >= 8 ? NT_64_DEEP : NT_64;
+    return tiles128 >= 384 ? NT_128 : NT_64;
 }
 template <typename K> static void set_lds(K kern, int bytes) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);

@@ -39,7 +39,6 @@ template <typename T, int BM, int BN, int NS> static void launch_pair_v(PairPara
 template <typename T> static int launch_pair_t(PairParams& pp, hipStream_t st) {
     switch (nt_variant(pp.nt)) {
         case NT_128:     launch_pair_v<T, 128, 128, 3>(pp, st); break;
-        case NT_64_DEEP: launch_pair_v<T, 64, 64, 8>(pp, st); break;
         default:         launch_pair_v<T, 64, 64, 4>(pp, st); break;
     }
     C1V_LAUNCH_CHECK();
