@@ -26,7 +26,7 @@ class Epilogue(C.Structure):
     _fields_ = [('bias', C.c_void_p), ('relu', C.c_int32), ('row_mode', C.c_int32), ('reshape_w', C.c_int32),
                 ('dst', Seq), ('act', Seq), ('act_rowmul', C.c_int32), ('act_scale', C.c_float),
                 ('sel', C.c_void_p), ('sel_bstride', C.c_int64), ('sel_cp', C.c_int32),
-                ('keep', C.c_void_p), ('keep_scale', C.c_float)]
+                ('keep', C.c_void_p), ('keep_scale', C.c_float), ('bias_row_w', C.c_int32)]
 
 
 class ConvArgs(C.Structure):

@@ -96,6 +96,7 @@ struct EpiDev {
     uint8_t* sel; int64_t sel_bstride; int sel_cp;
     const uint8_t* keep; float keep_scale;
     int M, Le, nrows, N;
+    int bias_row_w;       // c1v_epilogue::bias_row_w
     int fastw;            // 4 / 2: every group address of the epilogue is a multiple of that many elements (vector path); 0: element-wise
 };
 

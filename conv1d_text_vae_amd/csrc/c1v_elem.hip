@@ -4,6 +4,21 @@
 #include "c1v_common.h"
 #include "c1v_lossred.h"
 
+// index of the descriptor that owns block `blk`: descriptors are sorted by first_block (the first one starts at 0).
+// All lanes of a wave look at one descriptor each, so the search is one round of independent loads per 64 descriptors
+// (a serial scan cost one dependent global-load latency per descriptor).
+template <typename D>
+__device__ __forceinline__ int find_desc(const D* __restrict__ descs, int n_desc, int blk) {
+    const int lane = threadIdx.x & 63;
+    int found = 0;
+    for (int base = 0; base < n_desc; base += 64) {
+        const int i = base + lane;
+        const bool le = i < n_desc && descs[i].first_block <= blk;
+        found += __popcll(__ballot(le));
+    }
+    return found - 1;
+}
+
 // ------------------------------------------------------------------------------------------------------
 // input packing
 // ------------------------------------------------------------------------------------------------------
@@ -98,8 +113,7 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const c1v_pack_desc* 
     // segments.  Blocks are dealt to descriptors by `first_block`; within a descriptor the tile index enumerates
     // (tap, c tile, n tile).
     __shared__ float tile[32][33];
-    int di = 0;
-    while (di + 1 < n_desc && (int)blockIdx.x >= descs[di + 1].first_block) ++di;
+    const int di = find_desc(descs, n_desc, (int)blockIdx.x);
     const c1v_pack_desc d = descs[di];
     const int tc = (d.c_count + 31) >> 5, tn = (d.n_count + 31) >> 5;
     int bi = (int)blockIdx.x - d.first_block;
@@ -241,15 +255,18 @@ struct LossRedDev { const float* xent_rows; const int* ids; const float* kl_b; i
 
 __global__ __launch_bounds__(256) void grad_finalize_kernel(const c1v_seg_desc* __restrict__ segs, int n_seg, float* __restrict__ grad,
                                                             float* __restrict__ sq_partial, int seg_blocks, LossRedDev lr) {
-    if ((int)blockIdx.x >= seg_blocks) {           // the extra block of c1v_grad_finalize_loss: the step's loss scalars
+    // with loss scalars (c1v_grad_finalize_loss) block 0 computes them -- dispatched first, so its serial tail hides
+    // behind the segment blocks -- and the segment blocks are numbered from 1
+    const int first = (int)gridDim.x - seg_blocks;
+    if ((int)blockIdx.x < first) {
         loss_reduce_body(lr.xent_rows, lr.ids, lr.kl_b, lr.B, lr.T, lr.B_global, lr.out3, lr.xent_b);
         return;
     }
+    const int blk = (int)blockIdx.x - first;
     __shared__ float red[4];
-    int si = 0;
-    while (si + 1 < n_seg && (int)blockIdx.x >= segs[si + 1].first_block) ++si;
+    const int si = find_desc(segs, n_seg, blk);
     const c1v_seg_desc d = segs[si];
-    const int64_t base = (int64_t)((int)blockIdx.x - d.first_block) * C1V_CHUNK;
+    const int64_t base = (int64_t)(blk - d.first_block) * C1V_CHUNK;
     float sq = 0.f;
     // slabs, segment offsets and counts are multiples of 4 floats except for a tail: float4 body, scalar tail
     const bool vec = (d.count % 4 == 0) && (d.slab_stride % 4 == 0) && (d.rep_stride % 4 == 0) && (d.offset % 4 == 0) &&
@@ -283,7 +300,7 @@ __global__ __launch_bounds__(256) void grad_finalize_kernel(const c1v_seg_desc* 
         }
     }
     sq = block_sum_256(sq, red);
-    if (threadIdx.x == 0 && sq_partial) sq_partial[blockIdx.x] = sq;
+    if (threadIdx.x == 0 && sq_partial) sq_partial[blk] = sq;
 }
 
 extern "C" int c1v_grad_finalize(const c1v_seg_desc* segs, int32_t n_seg, int32_t total_blocks, float* grad, float* sq_partial, void* stream) {
@@ -503,8 +520,7 @@ extern "C" int c1v_philox_bernoulli(uint8_t* out, int64_t n, float keep_prob, ui
 // several RNG requests in one launch (one training step draws eps + two dropout masks)
 __global__ __launch_bounds__(256) void philox_multi_kernel(const c1v_rng_desc* __restrict__ descs, int n_desc, uint64_t seed,
                                                            const uint64_t* __restrict__ ctr) {
-    int di = 0;
-    while (di + 1 < n_desc && (int)blockIdx.x >= descs[di + 1].first_block) ++di;
+    const int di = find_desc(descs, n_desc, (int)blockIdx.x);
     const c1v_rng_desc d = descs[di];
     const uint64_t offset = d.offset + (ctr ? ctr[0] * d.ctr_mul : 0);
     const uint64_t blk = (offset >> 2) + (uint64_t)((int)blockIdx.x - d.first_block) * 256 + threadIdx.x;

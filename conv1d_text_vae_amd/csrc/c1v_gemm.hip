@@ -75,12 +75,13 @@ int c1v_fill_epi(const c1v_epilogue& e, EpiDev& d, int M, int Le, int nrows, int
     d.act = e.act.data; d.act_dtype = e.act.dtype; d.act_bstride = e.act.bstride; d.act_off = e.act.off;
     d.act_cp = e.act.cp; d.act_rowmul = e.act_rowmul > 0 ? e.act_rowmul : 1; d.act_scale = e.act_scale;
     d.sel = e.sel; d.sel_bstride = e.sel_bstride; d.sel_cp = e.sel_cp;
-    d.keep = e.keep; d.keep_scale = e.keep_scale;
+    d.keep = e.keep; d.keep_scale = e.keep_scale; d.bias_row_w = e.bias_row_w;
     d.M = M; d.Le = Le; d.nrows = nrows; d.N = N;
     C1V_REQUIRE(e.dst.data != nullptr, "epilogue has no destination");
     C1V_REQUIRE(e.row_mode >= C1V_ROW_STORE && e.row_mode <= C1V_ROW_UNPOOL, "bad row_mode %d", e.row_mode);
     C1V_REQUIRE(e.row_mode != C1V_ROW_UNPOOL || e.sel != nullptr, "UNPOOL needs sel");
     C1V_REQUIRE(e.reshape_w <= 0 || (e.row_mode == C1V_ROW_STORE || e.row_mode == C1V_ROW_UNPOOL), "reshape_w only with STORE/UNPOOL");
+    C1V_REQUIRE(e.bias_row_w == 0 || (e.reshape_w > 0 && e.bias_row_w > 0 && e.bias_row_w <= e.reshape_w), "bias_row_w %d needs reshape_w >= it", e.bias_row_w);
     const int c_max = e.reshape_w > 0 ? e.reshape_w : N;
     C1V_REQUIRE(c_max <= e.dst.cp, "destination row pitch %d is smaller than %d channels", e.dst.cp, c_max);
     // widest vector width at which every 4-channel group of the epilogue stays aligned (see epi_load / epi_finish)
@@ -100,5 +101,6 @@ int c1v_fill_epi(const c1v_epilogue& e, EpiDev& d, int M, int Le, int nrows, int
         if (ok) d.fastw = vw;
     }
     if (const char* env = getenv("C1V_EPI_ELEMENTWISE")) if (env[0] == '1') d.fastw = 0;     // diagnostic: force the element-wise path
+    if (getenv("C1V_EPI_TRACE")) fprintf(stderr, "c1v epilogue: mode %d M %d N %d reshape_w %d dst_cp %d -> vector width %d\n", e.row_mode, M, N, e.reshape_w, e.dst.cp, d.fastw);
     return 0;
 }

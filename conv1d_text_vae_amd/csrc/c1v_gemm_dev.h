@@ -520,7 +520,15 @@ __device__ __forceinline__ void nt_body(const NtParams& p, const int bx, const i
     EpiState es;
     {
         const int nbias = n0 + 4 * (tid % (BN / 4));
-        if (p.e.bias) {
+        if (p.e.bias && p.e.bias_row_w > 0) {           // rows padded to reshape_w channels: bias index = t * bias_row_w + c
+            const int tb = nbias / p.e.reshape_w, cb = nbias - tb * p.e.reshape_w;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                int t2 = tb, c2 = cb + k;
+                if (c2 >= p.e.reshape_w) { c2 -= p.e.reshape_w; ++t2; }
+                bias4[k] = (nbias + k < p.e.N && c2 < p.e.bias_row_w) ? p.e.bias[t2 * p.e.bias_row_w + c2] : 0.0f;
+            }
+        } else if (p.e.bias) {
             if (fastw == 4) {
                 if (nbias < p.e.N) { const float4 b = *(const float4*)(p.e.bias + nbias); bias4[0] = b.x; bias4[1] = b.y; bias4[2] = b.z; bias4[3] = b.w; }
             } else if (fastw == 2) {

@@ -73,6 +73,9 @@ typedef struct c1v_epilogue {
     int32_t        sel_cp;
     const uint8_t* keep;        /* dropout keep mask, same indexing as sel */
     float          keep_scale;
+    int32_t        bias_row_w;  /* with reshape_w: the GEMM was laid out with every (t, .) row padded from bias_row_w up to
+                                   reshape_w channels (zero weight rows) so that the vector epilogue applies to widths that
+                                   are not multiples of 4; bias index = t*bias_row_w + c, pad channels get 0.  0 = no padding */
 } c1v_epilogue;
 
 /* ---- a1 / a6 / a7: Conv1D('valid'|'same') and Conv2DTranspose((k,1)) forward (:1227-1280) -------------
