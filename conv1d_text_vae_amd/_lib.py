@@ -82,14 +82,14 @@ class LatentArgs(C.Structure):
 
 class L2NormArgs(C.Structure):
     _fields_ = [('y', C.c_void_p), ('M', C.c_int32), ('V', C.c_int32), ('ldy', C.c_int64), ('yhat', C.c_void_p),
-                ('dtype', C.c_int32), ('kp', C.c_int32), ('rnorm', C.c_void_p), ('qscale', C.c_float)]
+                ('dtype', C.c_int32), ('kp', C.c_int32), ('rnorm', C.c_void_p), ('qscale', C.c_float), ('pos', C.c_void_p)]
 
 
 class XentAccumArgs(C.Structure):
     _fields_ = [('yhat', C.c_void_p), ('dtype', C.c_int32), ('M', C.c_int32), ('kp', C.c_int32), ('w', C.c_void_p),
                 ('N', C.c_int32), ('n_pad', C.c_int32), ('ut', C.c_void_p), ('m_pad', C.c_int32),
                 ('splits', C.c_int32), ('need_u', C.c_int32), ('ones_col', C.c_int32), ('logits', C.c_void_p),
-                ('n_chunk', C.c_int32)]
+                ('n_chunk', C.c_int32), ('live_ctl', C.c_void_p)]
 
 
 class XentFinishArgs(C.Structure):
@@ -97,7 +97,7 @@ class XentFinishArgs(C.Structure):
                 ('ones_col', C.c_int32), ('yhat', C.c_void_p), ('w', C.c_void_p), ('dtype', C.c_int32),
                 ('rnorm', C.c_void_p), ('qscale', C.c_float), ('ids', C.c_void_p), ('B', C.c_int32), ('T', C.c_int32),
                 ('V', C.c_int32), ('B_global', C.c_int32), ('xent_rows', C.c_void_p), ('xent_b', C.c_void_p),
-                ('dy', Seq), ('y', C.c_void_p), ('ldy', C.c_int64)]
+                ('dy', Seq), ('y', C.c_void_p), ('ldy', C.c_int64), ('pos', C.c_void_p), ('live_ctl', C.c_void_p)]
 
 
 class SegDesc(C.Structure):
@@ -158,6 +158,7 @@ SYMBOLS = {
     'c1v_latent_head_fwd': ([_P(LatentArgs), C.c_void_p], C.c_int),
     'c1v_latent_head_bwd': ([_P(LatentArgs), C.c_void_p], C.c_int),
     'c1v_l2norm_rows': ([_P(L2NormArgs), C.c_void_p], C.c_int),
+    'c1v_live_rows': ([C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p], C.c_int),
     'c1v_cos_softmax_accum': ([_P(XentAccumArgs), C.c_void_p], C.c_int),
     'c1v_cos_softmax_xent_fwd': ([_P(XentAccumArgs), C.c_void_p], C.c_int),
     'c1v_cos_softmax_xent_bwd': ([_P(XentAccumArgs), C.c_void_p], C.c_int),

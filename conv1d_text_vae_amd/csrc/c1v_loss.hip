@@ -14,15 +14,22 @@
 #include "c1v_common.h"
 #include "c1v_lossred.h"
 
+constexpr int VS_BM_ROWS = 128;   // sample rows per workgroup of the vocabulary stream (== VS_BM below)
+
 // ------------------------------------------------------------------------------------------------------
 // l2 normalise rows: yhat = y * rsqrt(max(sum y^2, 1e-12)) * qscale      (K.l2_normalize, reference :1195)
 // ------------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void l2norm_rows_kernel(const float* __restrict__ y, int M, int V, int64_t ldy,
-                                                          T* __restrict__ yhat, int kp, float* __restrict__ rnorm, float qscale) {
+                                                          T* __restrict__ yhat, int kp, float* __restrict__ rnorm, float qscale,
+                                                          const int* __restrict__ pos) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
+    // live-row compaction (c1v_live_rows): a row without a target takes no part in the loss -- it is not normalised at
+    // all; the others land at their compact position
+    const int orow = pos ? pos[row] : row;
+    if (orow < 0) return;
     const float* yr = y + (int64_t)row * ldy;
     float ss = 0.f;
     for (int c = lane; c < V; c += 64) { const float v = yr[c]; ss += v * v; }
@@ -30,7 +37,42 @@ __global__ __launch_bounds__(256) void l2norm_rows_kernel(const float* __restric
     const float r = 1.0f / sqrtf(fmaxf(ss, 1e-12f));
     if (lane == 0 && rnorm) rnorm[row] = r;
     const float sc = r * qscale;
-    for (int c = lane; c < kp; c += 64) ElemTraits<T>::store(yhat, (int64_t)row * kp + c, c < V ? yr[c] * sc : 0.0f);
+    for (int c = lane; c < kp; c += 64) ElemTraits<T>::store(yhat, (int64_t)orow * kp + c, c < V ? yr[c] * sc : 0.0f);
+}
+
+// positions of the rows that have a target (ids[m] >= 0) in compact order, -1 for the others, and the work split of the
+// vocabulary stream over them:
+//   ctl[0] = n_live, ctl[1] = live row tiles (128 rows), ctl[2] = vocabulary splits per row tile, ctl[3] = tiles per split
+// The stream kernels are launched with a fixed grid of `items` workgroups (a captured graph cannot resize it); with fewer
+// live row tiles each one is cut into more vocabulary splits so that the grid still covers the chip.
+// One workgroup: every thread counts a run of consecutive rows, the runs are scanned through LDS.
+__global__ __launch_bounds__(1024) void live_rows_kernel(const int* __restrict__ ids, int M, int items, int vocab_tiles, int max_splits,
+                                                         int* __restrict__ pos, int* __restrict__ ctl) {
+    __shared__ int wsum[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int per = (M + 1023) / 1024;
+    const int m0 = tid * per;
+    int cnt = 0;
+    for (int i = 0; i < per; ++i) cnt += (m0 + i < M && ids[m0 + i] >= 0) ? 1 : 0;
+    int incl = cnt;                                    // inclusive scan inside the wave
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wave; ++w) base += wsum[w];
+    int p = base + incl - cnt;
+    for (int i = 0; i < per; ++i)
+        if (m0 + i < M) pos[m0 + i] = ids[m0 + i] >= 0 ? p++ : -1;
+    if (tid == 1023) {
+        const int live = base + incl;
+        const int tiles = (live + VS_BM_ROWS - 1) / VS_BM_ROWS;
+        int splits = tiles > 0 ? items / tiles : 1;
+        if (splits > max_splits) splits = max_splits;
+        if (splits > vocab_tiles) splits = vocab_tiles;
+        if (splits < 1) splits = 1;
+        ctl[0] = live; ctl[1] = tiles; ctl[2] = splits; ctl[3] = (vocab_tiles + splits - 1) / splits;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -50,7 +92,7 @@ extern "C" int c1v_debug_read(unsigned long long* dst, int n) {
 #define VS_T(i) do {} while (0)
 #endif
 constexpr int VS_BN = 64;     // vocabulary rows per LDS tile
-constexpr int VS_BM = 128;    // sample rows per workgroup (4 waves x 32)
+constexpr int VS_BM = VS_BM_ROWS;    // sample rows per workgroup (4 waves x 32)
 constexpr int VS_STAGES = 3;  // LDS ring of vocabulary tiles
 
 template <int CB> struct VsCfg {
@@ -74,15 +116,23 @@ template <int CB, int MODE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void vocab_stream_kernel(const bf16_raw* __restrict__ yhat, int M, const bf16_raw* __restrict__ w, int N, int n_base,
                          int tiles_total, int tiles_per_split, float* __restrict__ ut, int m_pad, int ones_col,
-                         float* __restrict__ part_score, int* __restrict__ part_idx) {
+                         float* __restrict__ part_score, int* __restrict__ part_idx, const int* __restrict__ ctl) {
     using Cfg = VsCfg<CB>;
     constexpr int KS = CB * 2;                     // 16-wide k steps of GEMM1
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, h = lane >> 5;
-    const int split = blockIdx.y;
-    const int m_row = blockIdx.x * VS_BM + wave * 32 + l31;
+    int bx = blockIdx.x, split = blockIdx.y;       // row tile, vocabulary split
+    if (ctl) {
+        // compacted rows (live_rows_kernel): the grid is a pool of workgroups, dealt to (row tile, split) on the device
+        const int live = ctl[0], splits = ctl[2];
+        const int item = blockIdx.x + gridDim.x * blockIdx.y;
+        bx = item / splits; split = item - bx * splits;
+        if (bx * VS_BM >= live) return;             // whole workgroup, before any barrier
+        M = live; tiles_per_split = ctl[3];
+    }
+    const int m_row = bx * VS_BM + wave * 32 + l31;
     const int t_begin = split * tiles_per_split;
     int t_end = t_begin + tiles_per_split;
     if (t_end > tiles_total) t_end = tiles_total;
@@ -307,14 +357,14 @@ void vocab_stream_kernel(const bf16_raw* __restrict__ yhat, int M, const bf16_ra
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tloop) :: "memory");
 #endif
 
-    const int m_out = blockIdx.x * VS_BM + wave * 32 + l31;
+    const int m_out = bx * VS_BM + wave * 32 + l31;
     if constexpr (MODE == VS_ACCUM) {
         // U^T[c][m] sits with m on the lane; the consumer wants rows of U.  Transpose one 32x32 block at a time through
         // this wave's private 4.5 KB of LDS (the W stages are dead after the loop's last barrier) and store 128-byte
         // row segments: UT[split][m][c].
         constexpr int TP = 36;                                  // floats per transposed row (32 + 4 pad)
         float* tw = (float*)smem + wave * 32 * TP;
-        float* o = ut + ((int64_t)split * m_pad + blockIdx.x * VS_BM + wave * 32) * Cfg::KP;
+        float* o = ut + ((int64_t)split * m_pad + bx * VS_BM + wave * 32) * Cfg::KP;
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb) {
 #pragma unroll
@@ -361,7 +411,8 @@ __global__ __launch_bounds__(256) void xent_finish_kernel(const float* __restric
                                                           const T* __restrict__ yhat, const T* __restrict__ w,
                                                           const float* __restrict__ rnorm, float qscale,
                                                           const int* __restrict__ ids, int B, int T_len, int V, int B_global,
-                                                          float* __restrict__ xent_rows, c1v_seq dy, const float* __restrict__ y, int64_t ldy) {
+                                                          float* __restrict__ xent_rows, c1v_seq dy, const float* __restrict__ y, int64_t ldy,
+                                                          const int* __restrict__ pos, const int* __restrict__ ctl) {
     // one wave per sample row; everything is row-wise and coalesced.  The projection that backpropagates through the
     // l2-normalisation uses yhat = y * rnorm in fp32 when `y` is given: a bf16-rounded yhat leaves a residue ALONG y,
     // which the transposed final conv amplifies coherently (measured: 6x larger relative error downstream).
@@ -372,16 +423,27 @@ __global__ __launch_bounds__(256) void xent_finish_kernel(const float* __restric
     const int b = m / T_len, t = m - b * T_len;
     const int id = ids[m];
     const bool mask = id >= 0;
+    // live-row compaction: `cr` is the row of yhat / ut that belongs to sample row m; rows without a target have none
+    const int cr = pos ? pos[m] : m;
+    if (ctl) splits = ctl[2];
+    if (cr < 0) {                                   // wave-uniform: no loss term, zero gradient
+        if (lane == 0) xent_rows[m] = 0.0f;
+        if (dy.data != nullptr) {
+            const int64_t drow0 = (int64_t)b * dy.bstride + (int64_t)(dy.off + t) * dy.cp;
+            for (int c = lane; c < V; c += 64) store_any(dy.data, dy.dtype, drow0 + c, 0.0f);
+        }
+        return;
+    }
     const float inv_q = 1.0f / qscale;
     const float inv_tau_eff = qscale * 0.6931471805599453f;     // 1/tau = qscale * ln 2
     float sumexp = 0.f;
-    for (int sp = 0; sp < splits; ++sp) sumexp += ut[((int64_t)sp * m_pad + m) * kp + ones_col];
+    for (int sp = 0; sp < splits; ++sp) sumexp += ut[((int64_t)sp * m_pad + cr) * kp + ones_col];
     float cnt = 0.f;
     for (int tt = lane; tt < T_len; tt += 64) cnt += ids[b * T_len + tt] >= 0 ? 1.f : 0.f;
     float st = 0.f;
     if (mask)
         for (int c = lane; c < V; c += 64)
-            st += ElemTraits<T>::load(yhat, (int64_t)m * kp + c) * ElemTraits<T>::load(w, (int64_t)id * kp + c);
+            st += ElemTraits<T>::load(yhat, (int64_t)cr * kp + c) * ElemTraits<T>::load(w, (int64_t)id * kp + c);
     cnt = wave_sum(cnt);
     st = wave_sum(st);
     const float p_t = exp2f(st) / sumexp;
@@ -409,9 +471,9 @@ __global__ __launch_bounds__(256) void xent_finish_kernel(const float* __restric
             uu[k] = 0.f; yy[k] = 0.f;
             if (c < V) {
                 float u = 0.f;
-                for (int sp = 0; sp < splits; ++sp) u += ut[((int64_t)sp * m_pad + m) * kp + c];
+                for (int sp = 0; sp < splits; ++sp) u += ut[((int64_t)sp * m_pad + cr) * kp + c];
                 uu[k] = coef * (u * inv_se - ElemTraits<T>::load(w, (int64_t)id * kp + c));
-                yy[k] = y ? y[(int64_t)m * ldy + c] * rn : ElemTraits<T>::load(yhat, (int64_t)m * kp + c) * inv_q;
+                yy[k] = y ? y[(int64_t)m * ldy + c] * rn : ElemTraits<T>::load(yhat, (int64_t)cr * kp + c) * inv_q;
                 dot += uu[k] * yy[k];
             }
         }
@@ -425,16 +487,16 @@ __global__ __launch_bounds__(256) void xent_finish_kernel(const float* __restric
     }
     for (int c = lane; c < V; c += 64) {
         float u = 0.f;
-        for (int sp = 0; sp < splits; ++sp) u += ut[((int64_t)sp * m_pad + m) * kp + c];
+        for (int sp = 0; sp < splits; ++sp) u += ut[((int64_t)sp * m_pad + cr) * kp + c];
         const float dyh = coef * (u * inv_se - ElemTraits<T>::load(w, (int64_t)id * kp + c));
-        dot += dyh * (y ? y[(int64_t)m * ldy + c] * rn : ElemTraits<T>::load(yhat, (int64_t)m * kp + c) * inv_q);
+        dot += dyh * (y ? y[(int64_t)m * ldy + c] * rn : ElemTraits<T>::load(yhat, (int64_t)cr * kp + c) * inv_q);
     }
     dot = wave_sum(dot);
     for (int c = lane; c < V; c += 64) {
         float u = 0.f;
-        for (int sp = 0; sp < splits; ++sp) u += ut[((int64_t)sp * m_pad + m) * kp + c];
+        for (int sp = 0; sp < splits; ++sp) u += ut[((int64_t)sp * m_pad + cr) * kp + c];
         const float dyh = coef * (u * inv_se - ElemTraits<T>::load(w, (int64_t)id * kp + c));
-        const float yh = y ? y[(int64_t)m * ldy + c] * rn : ElemTraits<T>::load(yhat, (int64_t)m * kp + c) * inv_q;
+        const float yh = y ? y[(int64_t)m * ldy + c] * rn : ElemTraits<T>::load(yhat, (int64_t)cr * kp + c) * inv_q;
         store_any(dy.data, dy.dtype, drow + c, normal ? (dyh - yh * dot) * rn : dyh * rn);
     }
 }
@@ -517,34 +579,34 @@ extern "C" int c1v_l2norm_rows(const c1v_l2norm_args* a, void* stream) {
     C1V_REQUIRE(a->M > 0 && a->V > 0 && a->kp >= a->V, "l2norm: bad shape M=%d V=%d kp=%d", a->M, a->V, a->kp);
     dim3 grid((unsigned)c1v_cdiv(a->M, 4));
     if (a->dtype == C1V_F32)
-        hipLaunchKernelGGL(l2norm_rows_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, a->y, a->M, a->V, a->ldy, (float*)a->yhat, a->kp, a->rnorm, a->qscale);
+        hipLaunchKernelGGL(l2norm_rows_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, a->y, a->M, a->V, a->ldy, (float*)a->yhat, a->kp, a->rnorm, a->qscale, a->pos);
     else
-        hipLaunchKernelGGL(l2norm_rows_kernel<bf16_raw>, grid, dim3(256), 0, (hipStream_t)stream, a->y, a->M, a->V, a->ldy, (bf16_raw*)a->yhat, a->kp, a->rnorm, a->qscale);
+        hipLaunchKernelGGL(l2norm_rows_kernel<bf16_raw>, grid, dim3(256), 0, (hipStream_t)stream, a->y, a->M, a->V, a->ldy, (bf16_raw*)a->yhat, a->kp, a->rnorm, a->qscale, a->pos);
     C1V_LAUNCH_CHECK();
     return 0;
 }
 
 template <int CB, int MODE>
 static int launch_vs(const bf16_raw* yhat, int M, const bf16_raw* w, int N, int n_base, int splits, float* ut, int m_pad, int ones_col,
-                     float* ps, int* pi, hipStream_t st) {
+                     float* ps, int* pi, const int* ctl, hipStream_t st) {
     using Cfg = VsCfg<CB>;
     static bool once = (hipFuncSetAttribute((const void*)vocab_stream_kernel<CB, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, VS_STAGES * Cfg::STAGE), true);
     (void)once;
     const int tiles_total = (int)c1v_cdiv(N, VS_BN);
     const int tps = (int)c1v_cdiv(tiles_total, splits);
     dim3 grid((unsigned)(m_pad / VS_BM), (unsigned)splits);
-    hipLaunchKernelGGL((vocab_stream_kernel<CB, MODE>), grid, dim3(256), VS_STAGES * Cfg::STAGE, st, yhat, M, w, N, n_base, tiles_total, tps, ut, m_pad, ones_col, ps, pi);
+    hipLaunchKernelGGL((vocab_stream_kernel<CB, MODE>), grid, dim3(256), VS_STAGES * Cfg::STAGE, st, yhat, M, w, N, n_base, tiles_total, tps, ut, m_pad, ones_col, ps, pi, ctl);
     C1V_LAUNCH_CHECK();
     return 0;
 }
 
 template <int MODE>
 static int dispatch_vs(int kp, const bf16_raw* yhat, int M, const bf16_raw* w, int N, int n_base, int splits, float* ut, int m_pad, int ones_col,
-                       float* ps, int* pi, hipStream_t st) {
+                       float* ps, int* pi, const int* ctl, hipStream_t st) {
     switch (kp) {
-        case 32:  return launch_vs<1, MODE>(yhat, M, w, N, n_base, splits, ut, m_pad, ones_col, ps, pi, st);
-        case 64:  return launch_vs<2, MODE>(yhat, M, w, N, n_base, splits, ut, m_pad, ones_col, ps, pi, st);
-        case 320: return launch_vs<10, MODE>(yhat, M, w, N, n_base, splits, ut, m_pad, ones_col, ps, pi, st);
+        case 32:  return launch_vs<1, MODE>(yhat, M, w, N, n_base, splits, ut, m_pad, ones_col, ps, pi, ctl, st);
+        case 64:  return launch_vs<2, MODE>(yhat, M, w, N, n_base, splits, ut, m_pad, ones_col, ps, pi, ctl, st);
+        case 320: return launch_vs<10, MODE>(yhat, M, w, N, n_base, splits, ut, m_pad, ones_col, ps, pi, ctl, st);
         default: return 1;   // no fused instantiation for this width
     }
 }
@@ -610,12 +672,26 @@ extern "C" int c1v_cos_softmax_accum(const c1v_xent_accum_args* a, void* stream)
     C1V_REQUIRE(a->ones_col >= 0 && a->ones_col < a->kp, "cos_softmax_accum: ones_col out of range");
     hipStream_t st = (hipStream_t)stream;
     if (a->dtype == C1V_BF16) {
+        if (a->live_ctl) {
+            const bool fused = a->kp == 32 || a->kp == 64 || a->kp == 320;
+            C1V_REQUIRE(fused, "cos_softmax_accum: live_ctl needs the fused stream kernel (kp = 32, 64 or 320; got %d)", a->kp);
+        }
         int rc = a->need_u
-            ? dispatch_vs<VS_ACCUM>(a->kp, (const bf16_raw*)a->yhat, a->M, (const bf16_raw*)a->w, a->N, 0, a->splits, a->ut, a->m_pad, a->ones_col, nullptr, nullptr, st)
-            : dispatch_vs<VS_SUMEXP>(a->kp, (const bf16_raw*)a->yhat, a->M, (const bf16_raw*)a->w, a->N, 0, a->splits, a->ut, a->m_pad, a->ones_col, nullptr, nullptr, st);
+            ? dispatch_vs<VS_ACCUM>(a->kp, (const bf16_raw*)a->yhat, a->M, (const bf16_raw*)a->w, a->N, 0, a->splits, a->ut, a->m_pad, a->ones_col, nullptr, nullptr, a->live_ctl, st)
+            : dispatch_vs<VS_SUMEXP>(a->kp, (const bf16_raw*)a->yhat, a->M, (const bf16_raw*)a->w, a->N, 0, a->splits, a->ut, a->m_pad, a->ones_col, nullptr, nullptr, a->live_ctl, st);
         if (rc <= 0) return rc;
     }
+    C1V_REQUIRE(a->live_ctl == nullptr, "cos_softmax_accum: live_ctl is only supported by the fused bf16 stream kernel");
     return xent_accum_unfused(a, st);
+}
+
+extern "C" int c1v_live_rows(const int32_t* ids, int32_t M, int32_t items, int32_t vocab_tiles, int32_t max_splits, int32_t* pos, int32_t* ctl,
+                             void* stream) {
+    C1V_REQUIRE(ids && pos && ctl && M > 0 && items > 0 && vocab_tiles > 0 && max_splits > 0, "live_rows: bad argument");
+    C1V_REQUIRE(items >= (int)c1v_cdiv(M, VS_BM), "live_rows: the stream grid (%d workgroups) must cover all %d row tiles", items, (int)c1v_cdiv(M, VS_BM));
+    hipLaunchKernelGGL(live_rows_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, ids, M, items, vocab_tiles, max_splits, pos, ctl);
+    C1V_LAUNCH_CHECK();
+    return 0;
 }
 extern "C" int c1v_cos_softmax_xent_fwd(const c1v_xent_accum_args* a, void* stream) {
     C1V_REQUIRE(a, "null argument");
@@ -636,10 +712,10 @@ extern "C" int c1v_cos_softmax_finish(const c1v_xent_finish_args* a, void* strea
     dim3 grid((unsigned)c1v_cdiv(M, 4));
     if (a->dtype == C1V_F32)
         hipLaunchKernelGGL(xent_finish_kernel<float>, grid, dim3(256), lds, (hipStream_t)stream, a->ut, a->splits, a->kp, a->m_pad, a->ones_col,
-                           (const float*)a->yhat, (const float*)a->w, a->rnorm, a->qscale, a->ids, a->B, a->T, a->V, a->B_global, a->xent_rows, a->dy, a->y, a->ldy);
+                           (const float*)a->yhat, (const float*)a->w, a->rnorm, a->qscale, a->ids, a->B, a->T, a->V, a->B_global, a->xent_rows, a->dy, a->y, a->ldy, a->pos, a->live_ctl);
     else
         hipLaunchKernelGGL(xent_finish_kernel<bf16_raw>, grid, dim3(256), lds, (hipStream_t)stream, a->ut, a->splits, a->kp, a->m_pad, a->ones_col,
-                           (const bf16_raw*)a->yhat, (const bf16_raw*)a->w, a->rnorm, a->qscale, a->ids, a->B, a->T, a->V, a->B_global, a->xent_rows, a->dy, a->y, a->ldy);
+                           (const bf16_raw*)a->yhat, (const bf16_raw*)a->w, a->rnorm, a->qscale, a->ids, a->B, a->T, a->V, a->B_global, a->xent_rows, a->dy, a->y, a->ldy, a->pos, a->live_ctl);
     C1V_LAUNCH_CHECK();
     return 0;
 }
@@ -666,7 +742,7 @@ extern "C" int c1v_vocab_argmax(const c1v_vocab_argmax_args* a, void* stream) {
     if (a->dtype == C1V_BF16 && a->part_score && a->part_idx && a->splits > 0 && a->m_pad % VS_BM == 0 && a->m_pad >= a->M &&
         a->n_pad % VS_BN == 0 && a->n_pad >= a->N) {
         int rc = dispatch_vs<VS_ARGMAX>(a->kp, (const bf16_raw*)a->q, a->M, (const bf16_raw*)a->w, a->N, a->n_base, a->splits, nullptr, a->m_pad, 0,
-                                        a->part_score, a->part_idx, st);
+                                        a->part_score, a->part_idx, nullptr, st);
         if (rc < 0) return rc;
         if (rc == 0) {
             hipLaunchKernelGGL(argmax_merge_kernel, dim3((unsigned)c1v_cdiv(a->M, 256)), dim3(256), 0, st, a->part_score, a->part_idx, a->splits,

@@ -257,7 +257,15 @@ class VAEEngine:
             spc = 8 if self.n_chunk >= 2048 else 1
             self.x_splits = chunks * spc
             self.logits = torch.zeros((self.n_chunk + L.SLACK_ROWS) * self.m_pad, dtype=self.tdt, device=self.dev)
-        self.ut = torch.zeros(self.x_splits * self.kp * self.m_pad, dtype=torch.float32, device=self.dev)
+        # Live-row compaction of the loss stages (rows with ids < 0 -- the padding behind the end of a text -- have zero
+        # loss and zero gradient): the fused stream kernel then runs on the compacted rows and its fixed grid is re-dealt
+        # on the device into more vocabulary splits per row tile (c1v_live_rows), up to max_splits slabs of `ut`.
+        self.compact = fused and os.environ.get('C1V_LIVE_ROWS', '1') == '1'
+        tiles_m = max(1, self.m_pad // 128)
+        self.max_splits = max(self.x_splits, min(tiles, 16, (4 * 256) // tiles_m)) if self.compact else self.x_splits
+        self.row_pos = torch.full((self.m_pad,), -1, dtype=torch.int32, device=self.dev)
+        self.live_ctl = torch.zeros(4, dtype=torch.int32, device=self.dev)
+        self.ut = torch.zeros(self.max_splits * self.kp * self.m_pad, dtype=torch.float32, device=self.dev)
         if hasattr(self, '_ops_built'):
             self._build_ops()
 
@@ -439,18 +447,28 @@ class VAEEngine:
             return
 
         # ---- loss
+        f_live = self.lib.c1v_live_rows
+        pos_ptr = self.row_pos.data_ptr() if self.compact else None
+        ctl_ptr = self.live_ctl.data_ptr() if self.compact else None
+
+        def live_rows():
+            L.check(f_live(self.ids_in.data_ptr(), self.M, (self.m_pad // 128) * self.x_splits, self.n_pad // 64,
+                           self.max_splits, self.row_pos.data_ptr(), self.live_ctl.data_ptr(), self._stream()), 'c1v_live_rows')
+        self.ops_live_rows = [live_rows] if self.compact else []
+
         def loss_ops(train: bool):
             ops = [op('c1v_l2norm_rows', L.L2NormArgs(self.Y.t.data_ptr(), self.M, self.V, self.V, self.yhat.data_ptr(),
-                                                      self.code, self.kp, self.rnorm.data_ptr(), self.qscale))]
+                                                      self.code, self.kp, self.rnorm.data_ptr(), self.qscale, pos_ptr))]
             ops.append(op('c1v_cos_softmax_accum', L.XentAccumArgs(
                 self.yhat.data_ptr(), self.code, self.M, self.kp, self.w_vocab.data_ptr(), self.N, self.n_pad,
                 self.ut.data_ptr(), self.m_pad, self.x_splits, 1 if train else 0, self.ones_col,
-                self.logits.data_ptr() if self.logits is not None else None, self.n_chunk)))
+                self.logits.data_ptr() if self.logits is not None else None, self.n_chunk, ctl_ptr)))
             ops.append(op('c1v_cos_softmax_finish', L.XentFinishArgs(
                 self.ut.data_ptr(), self.x_splits, self.kp, self.m_pad, self.ones_col, self.yhat.data_ptr(),
                 self.w_vocab.data_ptr(), self.code, self.rnorm.data_ptr(), self.qscale, self.ids_in.data_ptr(), B,
                 g.output_text_size, self.V, self.Bg, self.xent_rows.data_ptr(), self.xent_b.data_ptr(),
-                self.dOf.seq() if train else _null_seq(), self.Y.t.data_ptr(), self.V)))
+                self.dOf.seq() if train else _null_seq(), self.Y.t.data_ptr(), self.V, pos_ptr, ctl_ptr)))
+            ops = self.ops_live_rows + ops
             f_red = self.lib.c1v_loss_reduce
 
             def red():
@@ -460,7 +478,10 @@ class VAEEngine:
             return ops, red
 
         self.ops_loss_train, self.op_loss_reduce = loss_ops(True)
+        n0 = len(self.ops_live_rows)
+        self.op_xent_accum, self.op_xent_finish = self.ops_loss_train[n0 + 1], self.ops_loss_train[n0 + 2]   # benchmarks
         self.ops_loss_eval, red_eval = loss_ops(False)
+        self.op_xent_accum_eval = self.ops_loss_eval[n0 + 1]
         self.ops_loss_eval = self.ops_loss_eval + [red_eval]
 
         # ---- backward

@@ -214,8 +214,9 @@ int c1v_latent_head_bwd(const c1v_latent_args*, void* stream);
 typedef struct c1v_l2norm_args {
     const float* y; int32_t M, V; int64_t ldy;
     void* yhat; int32_t dtype; int32_t kp;
-    float* rnorm;           /* 1/sqrt(max(sum y^2, eps)) */
+    float* rnorm;           /* 1/sqrt(max(sum y^2, eps)), indexed by the row of y */
     float qscale;
+    const int32_t* pos;     /* optional (c1v_live_rows): row m of y lands in row pos[m] of yhat; pos[m] < 0: row skipped */
 } c1v_l2norm_args;
 int c1v_l2norm_rows(const c1v_l2norm_args*, void* stream);
 
@@ -229,6 +230,9 @@ typedef struct c1v_xent_accum_args {
     int32_t ones_col;
     float* logits;    /* f32 path scratch [n_chunk][m_pad] */
     int32_t n_chunk;
+    const int32_t* live_ctl;   /* optional DEVICE int[4] from c1v_live_rows (fused bf16 kernel only): yhat holds ctl[0] compacted
+                                  rows; the grid of (m_pad/128) x splits workgroups is re-dealt on the device to ctl[1] row tiles
+                                  x ctl[2] vocabulary splits, so ut must hold max_splits slabs (see c1v_live_rows) */
 } c1v_xent_accum_args;
 int c1v_cos_softmax_accum(const c1v_xent_accum_args*, void* stream);
 
@@ -243,8 +247,17 @@ typedef struct c1v_xent_finish_args {
     float* xent_b;            /* [B] per-sample sum_t xent*mask / sum_t mask */
     c1v_seq dy;               /* or dy.data == NULL for loss only */
     const float* y; int64_t ldy;   /* optional fp32 decoder output [M][ldy]: yhat = y*rnorm in fp32 for the normalisation backward */
+    const int32_t* pos;            /* optional: compact row of yhat / ut for sample row m (c1v_live_rows); < 0: no target */
+    const int32_t* live_ctl;       /* optional: number of ut slabs = live_ctl[2] instead of `splits` */
 } c1v_xent_finish_args;
 int c1v_cos_softmax_finish(const c1v_xent_finish_args*, void* stream);
+/* Rows without a target (ids[m] < 0: padding behind the end of a text) contribute exactly zero to the loss and to its
+ * gradient (reference :1199-1201 multiplies by the mask), so the loss stages may run on the compacted live rows only:
+ *   pos[m] = index of row m among the rows with ids[m] >= 0, or -1
+ *   ctl[0] = n_live, ctl[1] = ceil(n_live/128) row tiles, ctl[2] = vocabulary splits per row tile
+ *            = clamp(items / ctl[1], 1, min(max_splits, vocab_tiles)), ctl[3] = ceil(vocab_tiles / ctl[2])
+ * `items` = workgroups of the c1v_cos_softmax_accum grid = (m_pad/128) * splits; vocab_tiles = n_pad/64. */
+int c1v_live_rows(const int32_t* ids, int32_t M, int32_t items, int32_t vocab_tiles, int32_t max_splits, int32_t* pos, int32_t* ctl, void* stream);
 int c1v_cos_softmax_xent_fwd(const c1v_xent_accum_args*, void* stream);   /* need_u = 0 alias */
 int c1v_cos_softmax_xent_bwd(const c1v_xent_accum_args*, void* stream);   /* need_u = 1 alias */
 
