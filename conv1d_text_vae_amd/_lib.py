@@ -124,6 +124,17 @@ class RngDesc(C.Structure):
                 ('first_block', C.c_int32), ('pad', C.c_int32)]
 
 
+class LiveRowsArgs(C.Structure):
+    _fields_ = [('ids', C.c_void_p), ('M', C.c_int32), ('items', C.c_int32), ('vocab_tiles', C.c_int32),
+                ('max_splits', C.c_int32), ('pos', C.c_void_p), ('ctl', C.c_void_p)]
+
+
+class StepPrologueArgs(C.Structure):
+    _fields_ = [('rng_descs', C.c_void_p), ('n_rng', C.c_int32), ('rng_blocks', C.c_int32), ('seed', C.c_uint64),
+                ('ctr', C.c_void_p), ('pack', C.POINTER(PackInputArgs)), ('gather', C.POINTER(GatherInputArgs)),
+                ('live', C.POINTER(LiveRowsArgs))]
+
+
 class VocabArgmaxArgs(C.Structure):
     _fields_ = [('q', C.c_void_p), ('dtype', C.c_int32), ('M', C.c_int32), ('kp', C.c_int32), ('w', C.c_void_p),
                 ('N', C.c_int32), ('n_pad', C.c_int32), ('n_base', C.c_int32), ('part_score', C.c_void_p),
@@ -184,6 +195,7 @@ SYMBOLS = {
                               C.c_uint64, C.c_void_p], C.c_int),
     'c1v_counter_add': ([C.c_void_p, C.c_uint64, C.c_void_p], C.c_int),
     'c1v_philox_multi': ([C.c_void_p, C.c_int32, C.c_int32, C.c_uint64, C.c_void_p, C.c_void_p], C.c_int),
+    'c1v_step_prologue': ([_P(StepPrologueArgs), C.c_void_p], C.c_int),
     'c1v_last_error': ([], C.c_char_p),
     'c1v_version': ([], C.c_int),
     'c1v_device_info': ([C.c_int32, _P(C.c_int32)], C.c_int),

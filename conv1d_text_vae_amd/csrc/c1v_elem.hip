@@ -33,38 +33,56 @@ __device__ __forceinline__ void store8(c1v_seq dst, int64_t idx, const float v[8
     }
 }
 
+// (blk, nblk): this block's index among the blocks of the job -- the jobs also run as block ranges of c1v_step_prologue
 template <typename T>
-__global__ __launch_bounds__(256) void pack_input_kernel(const float* __restrict__ src, int T_len, int C, c1v_seq dst) {
+__device__ __forceinline__ void pack_input_body(const float* __restrict__ src, int T_len, int C, const c1v_seq& dst, int blk, int nblk) {
     const int g8 = dst.cp >> 3;
     const int64_t total = (int64_t)dst.batch * T_len * g8;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int c0 = (int)(i % g8) * 8;
-        const int64_t row = i / g8;
-        const int t = (int)(row % T_len);
-        const int64_t b = row / T_len;
+    for (int64_t i = blk * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)nblk * blockDim.x) {
+        int c0, t;
+        int64_t row, b;
+        if (total < (1ll << 31)) {                     // 32-bit index arithmetic (64-bit divisions are several times slower)
+            const uint32_t i32 = (uint32_t)i, r32 = i32 / (uint32_t)g8, b32 = r32 / (uint32_t)T_len;
+            c0 = (int)(i32 - r32 * (uint32_t)g8) * 8; row = r32; t = (int)(r32 - b32 * (uint32_t)T_len); b = b32;
+        } else {
+            c0 = (int)(i % g8) * 8; row = i / g8; t = (int)(row % T_len); b = row / T_len;
+        }
         float v[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) v[k] = c0 + k < C ? src[row * C + c0 + k] : 0.0f;
         store8<T>(dst, b * dst.bstride + (int64_t)(dst.off + t) * dst.cp + c0, v);
     }
 }
+template <typename T>
+__global__ __launch_bounds__(256) void pack_input_kernel(const float* __restrict__ src, int T_len, int C, c1v_seq dst) {
+    pack_input_body<T>(src, T_len, C, dst, (int)blockIdx.x, (int)gridDim.x);
+}
 
 template <typename T>
-__global__ __launch_bounds__(256) void gather_input_kernel(const float* __restrict__ table, int64_t ld, const int* __restrict__ ids,
-                                                           int T_len, int C, c1v_seq dst) {
+__device__ __forceinline__ void gather_input_body(const float* __restrict__ table, int64_t ld, const int* __restrict__ ids,
+                                                  int T_len, int C, const c1v_seq& dst, int blk, int nblk) {
     const int g8 = dst.cp >> 3;
     const int64_t total = (int64_t)dst.batch * T_len * g8;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int c0 = (int)(i % g8) * 8;
-        const int64_t row = i / g8;
-        const int t = (int)(row % T_len);
-        const int64_t b = row / T_len;
+    for (int64_t i = blk * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)nblk * blockDim.x) {
+        int c0, t;
+        int64_t row, b;
+        if (total < (1ll << 31)) {
+            const uint32_t i32 = (uint32_t)i, r32 = i32 / (uint32_t)g8, b32 = r32 / (uint32_t)T_len;
+            c0 = (int)(i32 - r32 * (uint32_t)g8) * 8; row = r32; t = (int)(r32 - b32 * (uint32_t)T_len); b = b32;
+        } else {
+            c0 = (int)(i % g8) * 8; row = i / g8; t = (int)(row % T_len); b = row / T_len;
+        }
         const int id = ids[row];
         float v[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) v[k] = (c0 + k < C && id >= 0) ? table[(int64_t)id * ld + c0 + k] : 0.0f;
         store8<T>(dst, b * dst.bstride + (int64_t)(dst.off + t) * dst.cp + c0, v);
     }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void gather_input_kernel(const float* __restrict__ table, int64_t ld, const int* __restrict__ ids,
+                                                           int T_len, int C, c1v_seq dst) {
+    gather_input_body<T>(table, ld, ids, T_len, C, dst, (int)blockIdx.x, (int)gridDim.x);
 }
 
 static unsigned grid_for(int64_t n) {
@@ -518,12 +536,12 @@ extern "C" int c1v_philox_bernoulli(uint8_t* out, int64_t n, float keep_prob, ui
 }
 
 // several RNG requests in one launch (one training step draws eps + two dropout masks)
-__global__ __launch_bounds__(256) void philox_multi_kernel(const c1v_rng_desc* __restrict__ descs, int n_desc, uint64_t seed,
-                                                           const uint64_t* __restrict__ ctr) {
-    const int di = find_desc(descs, n_desc, (int)blockIdx.x);
+__device__ __forceinline__ void philox_multi_body(const c1v_rng_desc* __restrict__ descs, int n_desc, uint64_t seed,
+                                                  const uint64_t* __restrict__ ctr, int blkid) {
+    const int di = find_desc(descs, n_desc, blkid);
     const c1v_rng_desc d = descs[di];
     const uint64_t offset = d.offset + (ctr ? ctr[0] * d.ctr_mul : 0);
-    const uint64_t blk = (offset >> 2) + (uint64_t)((int)blockIdx.x - d.first_block) * 256 + threadIdx.x;
+    const uint64_t blk = (offset >> 2) + (uint64_t)(blkid - d.first_block) * 256 + threadIdx.x;
     if (blk > ((offset + d.n - 1) >> 2)) return;
     const uint4 w = philox4x32_10(make_uint4((uint32_t)blk, (uint32_t)(blk >> 32), (uint32_t)d.stream_id, (uint32_t)(d.stream_id >> 32)),
                                   (uint32_t)seed, (uint32_t)(seed >> 32));
@@ -551,6 +569,73 @@ __global__ __launch_bounds__(256) void philox_multi_kernel(const c1v_rng_desc* _
         }
     }
 }
+__global__ __launch_bounds__(256) void philox_multi_kernel(const c1v_rng_desc* __restrict__ descs, int n_desc, uint64_t seed,
+                                                           const uint64_t* __restrict__ ctr) {
+    philox_multi_body(descs, n_desc, seed, ctr, (int)blockIdx.x);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// step prologue: everything a step needs before its first GEMM and that depends on nothing but the inputs -- the random
+// draws, the encoder operand (pack or gather) and the live-row table of the loss -- in ONE launch (each was a 5-11 us
+// launch of its own on the critical path of a captured step)
+// ------------------------------------------------------------------------------------------------------
+struct PrologueDev {
+    const c1v_rng_desc* rng_descs; int n_rng, rng_blocks; uint64_t seed; const uint64_t* ctr;
+    int in_kind, in_dtype, in_blocks;            // 0 none, 1 pack, 2 gather
+    const float* src; int64_t ld; const int* in_ids; int T, C; c1v_seq dst;
+    int live_blocks; const int* ids; int M, items, vocab_tiles, max_splits; int* pos; int* ctl;
+};
+__global__ __launch_bounds__(256) void step_prologue_kernel(const PrologueDev d) {
+    int blk = (int)blockIdx.x;
+    if (blk < d.live_blocks) { live_rows_body(d.ids, d.M, d.items, d.vocab_tiles, d.max_splits, d.pos, d.ctl); return; }
+    blk -= d.live_blocks;
+    if (blk < d.rng_blocks) { philox_multi_body(d.rng_descs, d.n_rng, d.seed, d.ctr, blk); return; }
+    blk -= d.rng_blocks;
+    if (d.in_kind == 1) {
+        if (d.in_dtype == C1V_F32) pack_input_body<float>(d.src, d.T, d.C, d.dst, blk, d.in_blocks);
+        else pack_input_body<bf16_raw>(d.src, d.T, d.C, d.dst, blk, d.in_blocks);
+    } else if (d.in_kind == 2) {
+        if (d.in_dtype == C1V_F32) gather_input_body<float>(d.src, d.ld, d.in_ids, d.T, d.C, d.dst, blk, d.in_blocks);
+        else gather_input_body<bf16_raw>(d.src, d.ld, d.in_ids, d.T, d.C, d.dst, blk, d.in_blocks);
+    }
+}
+static int check_seq(const c1v_seq& s, const char* what);
+extern "C" int c1v_step_prologue(const c1v_step_prologue_args* a, void* stream) {
+    C1V_REQUIRE(a, "step_prologue: null argument");
+    C1V_REQUIRE(!(a->pack && a->gather), "step_prologue: pack and gather are alternatives");
+    PrologueDev d{};
+    if (a->n_rng > 0) {
+        C1V_REQUIRE(a->rng_descs && a->rng_blocks > 0, "step_prologue: bad rng table");
+        d.rng_descs = a->rng_descs; d.n_rng = a->n_rng; d.rng_blocks = a->rng_blocks; d.seed = a->seed; d.ctr = a->ctr;
+    }
+    if (a->pack || a->gather) {
+        const c1v_seq& dst = a->pack ? a->pack->dst : a->gather->dst;
+        const int T = a->pack ? a->pack->T : a->gather->T, C = a->pack ? a->pack->C : a->gather->C;
+        if (check_seq(dst, "step_prologue dst")) return -1;
+        C1V_REQUIRE(T > 0 && T <= dst.len && C > 0 && C <= dst.cp, "step_prologue: input shape mismatch (T=%d C=%d)", T, C);
+        C1V_REQUIRE(dst.cp % 8 == 0 && dst.bstride % 8 == 0 && ((uintptr_t)dst.data % 32) == 0, "step_prologue: dst rows must be 8-element groups, 32-byte aligned");
+        d.dst = dst; d.T = T; d.C = C; d.in_dtype = dst.dtype;
+        if (a->pack) { C1V_REQUIRE(a->pack->src, "step_prologue: null input"); d.in_kind = 1; d.src = a->pack->src; }
+        else {
+            C1V_REQUIRE(a->gather->table && a->gather->ids && a->gather->ld >= C, "step_prologue: bad gather table");
+            d.in_kind = 2; d.src = a->gather->table; d.ld = a->gather->ld; d.in_ids = a->gather->ids;
+        }
+        d.in_blocks = (int)grid_for((int64_t)dst.batch * T * (dst.cp / 8));
+    }
+    if (a->live) {
+        const c1v_live_rows_args* l = a->live;
+        C1V_REQUIRE(l->ids && l->pos && l->ctl && l->M > 0 && l->items > 0 && l->vocab_tiles > 0 && l->max_splits > 0, "step_prologue: bad live-row argument");
+        C1V_REQUIRE(l->items >= (int)c1v_cdiv(l->M, VS_BM_ROWS), "step_prologue: the stream grid must cover all row tiles");
+        d.live_blocks = 1; d.ids = l->ids; d.M = l->M; d.items = l->items; d.vocab_tiles = l->vocab_tiles; d.max_splits = l->max_splits;
+        d.pos = l->pos; d.ctl = l->ctl;
+    }
+    const int total = d.live_blocks + d.rng_blocks + d.in_blocks;
+    C1V_REQUIRE(total > 0, "step_prologue: nothing to do");
+    hipLaunchKernelGGL(step_prologue_kernel, dim3((unsigned)total), dim3(256), 0, (hipStream_t)stream, d);
+    C1V_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int c1v_philox_multi(const c1v_rng_desc* descs, int32_t n_desc, int32_t total_blocks, uint64_t seed, const uint64_t* ctr, void* stream) {
     C1V_REQUIRE(descs && n_desc > 0 && total_blocks > 0, "philox_multi: bad argument");
     hipLaunchKernelGGL(philox_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, descs, n_desc, seed, ctr);

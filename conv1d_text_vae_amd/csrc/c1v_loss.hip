@@ -14,8 +14,6 @@
 #include "c1v_common.h"
 #include "c1v_lossred.h"
 
-constexpr int VS_BM_ROWS = 128;   // sample rows per workgroup of the vocabulary stream (== VS_BM below)
-
 // ------------------------------------------------------------------------------------------------------
 // l2 normalise rows: yhat = y * rsqrt(max(sum y^2, 1e-12)) * qscale      (K.l2_normalize, reference :1195)
 // ------------------------------------------------------------------------------------------------------
@@ -40,39 +38,9 @@ __global__ __launch_bounds__(256) void l2norm_rows_kernel(const float* __restric
     for (int c = lane; c < kp; c += 64) ElemTraits<T>::store(yhat, (int64_t)orow * kp + c, c < V ? yr[c] * sc : 0.0f);
 }
 
-// positions of the rows that have a target (ids[m] >= 0) in compact order, -1 for the others, and the work split of the
-// vocabulary stream over them:
-//   ctl[0] = n_live, ctl[1] = live row tiles (128 rows), ctl[2] = vocabulary splits per row tile, ctl[3] = tiles per split
-// The stream kernels are launched with a fixed grid of `items` workgroups (a captured graph cannot resize it); with fewer
-// live row tiles each one is cut into more vocabulary splits so that the grid still covers the chip.
-// One workgroup: every thread counts a run of consecutive rows, the runs are scanned through LDS.
 __global__ __launch_bounds__(1024) void live_rows_kernel(const int* __restrict__ ids, int M, int items, int vocab_tiles, int max_splits,
                                                          int* __restrict__ pos, int* __restrict__ ctl) {
-    __shared__ int wsum[16];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int per = (M + 1023) / 1024;
-    const int m0 = tid * per;
-    int cnt = 0;
-    for (int i = 0; i < per; ++i) cnt += (m0 + i < M && ids[m0 + i] >= 0) ? 1 : 0;
-    int incl = cnt;                                    // inclusive scan inside the wave
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
-    if (lane == 63) wsum[wave] = incl;
-    __syncthreads();
-    int base = 0;
-    for (int w = 0; w < wave; ++w) base += wsum[w];
-    int p = base + incl - cnt;
-    for (int i = 0; i < per; ++i)
-        if (m0 + i < M) pos[m0 + i] = ids[m0 + i] >= 0 ? p++ : -1;
-    if (tid == 1023) {
-        const int live = base + incl;
-        const int tiles = (live + VS_BM_ROWS - 1) / VS_BM_ROWS;
-        int splits = tiles > 0 ? items / tiles : 1;
-        if (splits > max_splits) splits = max_splits;
-        if (splits > vocab_tiles) splits = vocab_tiles;
-        if (splits < 1) splits = 1;
-        ctl[0] = live; ctl[1] = tiles; ctl[2] = splits; ctl[3] = (vocab_tiles + splits - 1) / splits;
-    }
+    live_rows_body(ids, M, items, vocab_tiles, max_splits, pos, ctl);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -418,14 +386,15 @@ __global__ __launch_bounds__(256) void xent_finish_kernel(const float* __restric
     // which the transposed final conv amplifies coherently (measured: 6x larger relative error downstream).
     const int lane = threadIdx.x & 63;
     const int M = B * T_len;
-    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int m = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (m >= M) return;
     const int b = m / T_len, t = m - b * T_len;
     const int id = ids[m];
     const bool mask = id >= 0;
     // live-row compaction: `cr` is the row of yhat / ut that belongs to sample row m; rows without a target have none
-    const int cr = pos ? pos[m] : m;
-    if (ctl) splits = ctl[2];
+    // (wave-uniform values are moved to scalar registers so that the loops over the slabs stay scalar loops)
+    const int cr = pos ? __builtin_amdgcn_readfirstlane(pos[m]) : m;
+    if (ctl) splits = __builtin_amdgcn_readfirstlane(ctl[2]);
     if (cr < 0) {                                   // wave-uniform: no loss term, zero gradient
         if (lane == 0) xent_rows[m] = 0.0f;
         if (dy.data != nullptr) {

@@ -22,13 +22,34 @@ __device__ __forceinline__ void loss_reduce_body(const float* __restrict__ xent_
             const int ns = B - base < S ? B - base : S, n = ns * T_len;
             const float* xr = xent_rows + (int64_t)base * T_len;
             const int* ir = ids + (int64_t)base * T_len;
+            const bool vec = (n & 3) == 0 && (((((uintptr_t)xr) | ((uintptr_t)ir)) & 15) == 0);
+            if (vec) {
+                // 16-byte words: four times fewer (independent) requests per thread
 #pragma unroll 4
-            for (int i = tid; i < n; i += nthr) {
-                int bl = (int)(((float)i + 0.5f) * rcp);
-                int t = i - bl * T_len;
-                if (t < 0) { --bl; t += T_len; } else if (t >= T_len) { ++bl; t -= T_len; }
-                vx[bl * pitch + t] = xr[i];
-                vc[bl * pitch + t] = ir[i] >= 0 ? 1.f : 0.f;
+                for (int i4 = tid; i4 < (n >> 2); i4 += nthr) {
+                    const float4 xv = *(const float4*)(xr + 4 * i4);
+                    const int4 iv = *(const int4*)(ir + 4 * i4);
+                    const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+                    const int is[4] = {iv.x, iv.y, iv.z, iv.w};
+                    int bl = (int)(((float)(4 * i4) + 0.5f) * rcp);
+                    int t = 4 * i4 - bl * T_len;
+                    if (t < 0) { --bl; t += T_len; } else if (t >= T_len) { ++bl; t -= T_len; }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        vx[bl * pitch + t] = xs[k];
+                        vc[bl * pitch + t] = is[k] >= 0 ? 1.f : 0.f;
+                        if (++t == T_len) { t = 0; ++bl; }
+                    }
+                }
+            } else {
+#pragma unroll 4
+                for (int i = tid; i < n; i += nthr) {
+                    int bl = (int)(((float)i + 0.5f) * rcp);
+                    int t = i - bl * T_len;
+                    if (t < 0) { --bl; t += T_len; } else if (t >= T_len) { ++bl; t -= T_len; }
+                    vx[bl * pitch + t] = xr[i];
+                    vc[bl * pitch + t] = ir[i] >= 0 ? 1.f : 0.f;
+                }
             }
             __syncthreads();
             for (int bl = tid; bl < ns; bl += nthr) {
@@ -64,3 +85,60 @@ __device__ __forceinline__ void loss_reduce_body(const float* __restrict__ xent_
     }
 }
 
+
+constexpr int VS_BM_ROWS = 128;   // sample rows per workgroup of the vocabulary stream kernel
+
+// positions of the rows that have a target (ids[m] >= 0) in compact order, -1 for the others, and the work split of the
+// vocabulary stream over them:
+//   ctl[0] = n_live, ctl[1] = live row tiles (128 rows), ctl[2] = vocabulary splits per row tile, ctl[3] = tiles per split
+// The stream kernels are launched with a fixed grid of `items` workgroups (a captured graph cannot resize it); with fewer
+// live row tiles each one is cut into more vocabulary splits so that the grid still covers the chip.
+// One workgroup of any whole number of waves <= 16 (also run as a block of c1v_step_prologue): every thread owns a run of
+// consecutive rows (a multiple of 4, read and written as 16-byte words), the runs are scanned through LDS.
+__device__ __forceinline__ void live_rows_body(const int* __restrict__ ids, int M, int items, int vocab_tiles, int max_splits,
+                                               int* __restrict__ pos, int* __restrict__ ctl) {
+    __shared__ int wsum[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x, nwave = nthr >> 6;
+    const int per = ((M + nthr - 1) / nthr + 3) & ~3;
+    const int m0 = tid * per;
+    const bool vec = ((((uintptr_t)ids) | ((uintptr_t)pos)) & 15) == 0;
+    int cnt = 0;
+    for (int i = 0; i < per; i += 4) {
+        const int m = m0 + i;
+        if (vec && m + 3 < M) {
+            const int4 v = *(const int4*)(ids + m);
+            cnt += (v.x >= 0) + (v.y >= 0) + (v.z >= 0) + (v.w >= 0);
+        } else {
+            for (int k = 0; k < 4; ++k) cnt += (m + k < M && ids[m + k] >= 0) ? 1 : 0;
+        }
+    }
+    int incl = cnt;                                    // inclusive scan inside the wave
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wave; ++w) base += wsum[w];
+    int p = base + incl - cnt;
+    for (int i = 0; i < per; i += 4) {
+        const int m = m0 + i;
+        if (vec && m + 3 < M) {
+            const int4 v = *(const int4*)(ids + m);
+            int4 o;
+            o.x = v.x >= 0 ? p++ : -1; o.y = v.y >= 0 ? p++ : -1; o.z = v.z >= 0 ? p++ : -1; o.w = v.w >= 0 ? p++ : -1;
+            *(int4*)(pos + m) = o;
+        } else {
+            for (int k = 0; k < 4; ++k)
+                if (m + k < M) pos[m + k] = ids[m + k] >= 0 ? p++ : -1;
+        }
+    }
+    if (tid == nthr - 1) {
+        const int live = base + incl;
+        const int tiles = (live + VS_BM_ROWS - 1) / VS_BM_ROWS;
+        int splits = tiles > 0 ? items / tiles : 1;
+        if (splits > max_splits) splits = max_splits;
+        if (splits > vocab_tiles) splits = vocab_tiles;
+        if (splits < 1) splits = 1;
+        ctl[0] = live; ctl[1] = tiles; ctl[2] = splits; ctl[3] = (vocab_tiles + splits - 1) / splits;
+    }
+}

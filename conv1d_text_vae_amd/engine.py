@@ -371,8 +371,9 @@ class VAEEngine:
         self._graphs = {}
         op = self._op
         # ---- encoder forward (train / inference differ only in the dropout mask of the last layer)
-        self.ops_pack_in = [op('c1v_pack_input', L.PackInputArgs(self.x_in.data_ptr(), g.input_text_size,
-                                                                  g.input_vector_size, self.Xe[0].seq()))]
+        self._pack_in_args = L.PackInputArgs(self.x_in.data_ptr(), g.input_text_size, g.input_vector_size, self.Xe[0].seq())
+        self.ops_pack_in = [op('c1v_pack_input', self._pack_in_args)]
+        self._prologue_cache = {}
 
         def enc_fwd(train: bool):
             ops = []
@@ -455,6 +456,8 @@ class VAEEngine:
             L.check(f_live(self.ids_in.data_ptr(), self.M, (self.m_pad // 128) * self.x_splits, self.n_pad // 64,
                            self.max_splits, self.row_pos.data_ptr(), self.live_ctl.data_ptr(), self._stream()), 'c1v_live_rows')
         self.ops_live_rows = [live_rows] if self.compact else []
+        self._live_args = L.LiveRowsArgs(self.ids_in.data_ptr(), self.M, (self.m_pad // 128) * self.x_splits, self.n_pad // 64,
+                                         self.max_splits, self.row_pos.data_ptr(), self.live_ctl.data_ptr())
 
         def loss_ops(train: bool):
             ops = [op('c1v_l2norm_rows', L.L2NormArgs(self.Y.t.data_ptr(), self.M, self.V, self.V, self.yhat.data_ptr(),
@@ -468,6 +471,7 @@ class VAEEngine:
                 self.w_vocab.data_ptr(), self.code, self.rnorm.data_ptr(), self.qscale, self.ids_in.data_ptr(), B,
                 g.output_text_size, self.V, self.Bg, self.xent_rows.data_ptr(), self.xent_b.data_ptr(),
                 self.dOf.seq() if train else _null_seq(), self.Y.t.data_ptr(), self.V, pos_ptr, ctl_ptr)))
+            core = list(ops)
             ops = self.ops_live_rows + ops
             f_red = self.lib.c1v_loss_reduce
 
@@ -475,12 +479,12 @@ class VAEEngine:
                 L.check(f_red(self.xent_rows.data_ptr(), self.ids_in.data_ptr(), self.kl_b.data_ptr(), B,
                               g.output_text_size, self.Bg, self.loss_out.data_ptr(), self.xent_b.data_ptr(),
                               self._stream()), 'c1v_loss_reduce')
-            return ops, red
+            return ops, red, core
 
-        self.ops_loss_train, self.op_loss_reduce = loss_ops(True)
+        self.ops_loss_train, self.op_loss_reduce, self.ops_loss_train_core = loss_ops(True)
         n0 = len(self.ops_live_rows)
         self.op_xent_accum, self.op_xent_finish = self.ops_loss_train[n0 + 1], self.ops_loss_train[n0 + 2]   # benchmarks
-        self.ops_loss_eval, red_eval = loss_ops(False)
+        self.ops_loss_eval, red_eval, _ = loss_ops(False)
         self.op_xent_accum_eval = self.ops_loss_eval[n0 + 1]
         self.ops_loss_eval = self.ops_loss_eval + [red_eval]
 
@@ -686,6 +690,7 @@ class VAEEngine:
             L.check(f_c(ctr, 1, st), 'counter_add')
         self.ops_rng = [rng]
         self.ops_rng_eval = [rng_eval]
+        self._rng_n, self._rng_blocks = n_rd, rng_blocks
 
     # ------------------------------------------------------------------------------------------------------
     # execution
@@ -740,9 +745,11 @@ class VAEEngine:
         self._graphs = {k: v for k, v in self._graphs.items() if not k.endswith('@ids')}
 
     def _build_gather(self):
-        self.ops_gather_in = [self._op('c1v_gather_input', L.GatherInputArgs(
+        self._gather_args = L.GatherInputArgs(
             self.in_table.data_ptr(), self.in_table.shape[1], self.in_ids.data_ptr(), self.g.input_text_size,
-            self.g.input_vector_size, self.Xe[0].seq()))]
+            self.g.input_vector_size, self.Xe[0].seq())
+        self.ops_gather_in = [self._op('c1v_gather_input', self._gather_args)]
+        self._prologue_cache = {}
 
     def _in_ops(self, from_ids: bool):
         if not from_ids:
@@ -776,7 +783,24 @@ class VAEEngine:
             self._run(main_ops)
         main.wait_stream(side)
 
+    def _prologue_op(self, with_rng: bool, from_ids: bool):
+        """One launch for the random draws, the encoder operand and the live-row table of a train step (c1v_step_prologue)."""
+        key = (with_rng, from_ids)
+        if key not in self._prologue_cache:
+            if from_ids and self.ops_gather_in is None:
+                raise L.C1VError('from_ids=True needs set_input_table() first')
+            a = L.StepPrologueArgs(self.rng_descs.data_ptr() if with_rng else None, self._rng_n if with_rng else 0,
+                                   self._rng_blocks if with_rng else 0, self.seed, self.step_ctr.data_ptr(),
+                                   None if from_ids else C.pointer(self._pack_in_args),
+                                   C.pointer(self._gather_args) if from_ids else None,
+                                   C.pointer(self._live_args) if self.compact else None)
+            self._prologue_cache[key] = self._op('c1v_step_prologue', a)
+        return self._prologue_cache[key]
+
     def forward_ops(self, with_rng: bool, from_ids: bool = False):
+        if os.environ.get('C1V_PROLOGUE', '1') == '1':
+            return [self._prologue_op(with_rng, from_ids)] + self.ops_enc_train + self.ops_lat_train + self.ops_dec + \
+                self.ops_loss_train_core
         return (self.ops_rng if with_rng else []) + self._in_ops(from_ids) + self.ops_enc_train + self.ops_lat_train + \
             self.ops_dec + self.ops_loss_train
 

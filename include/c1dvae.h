@@ -258,6 +258,7 @@ int c1v_cos_softmax_finish(const c1v_xent_finish_args*, void* stream);
  *            = clamp(items / ctl[1], 1, min(max_splits, vocab_tiles)), ctl[3] = ceil(vocab_tiles / ctl[2])
  * `items` = workgroups of the c1v_cos_softmax_accum grid = (m_pad/128) * splits; vocab_tiles = n_pad/64. */
 int c1v_live_rows(const int32_t* ids, int32_t M, int32_t items, int32_t vocab_tiles, int32_t max_splits, int32_t* pos, int32_t* ctl, void* stream);
+typedef struct c1v_live_rows_args { const int32_t* ids; int32_t M, items, vocab_tiles, max_splits; int32_t* pos; int32_t* ctl; } c1v_live_rows_args;
 int c1v_cos_softmax_xent_fwd(const c1v_xent_accum_args*, void* stream);   /* need_u = 0 alias */
 int c1v_cos_softmax_xent_bwd(const c1v_xent_accum_args*, void* stream);   /* need_u = 1 alias */
 
@@ -344,6 +345,18 @@ int c1v_counter_add(uint64_t* ctr, uint64_t inc, void* stream);
  * request i owns blocks [first_block_i, first_block_{i+1}) with ceil((n + 3) / 1024) + 1 blocks each */
 typedef struct c1v_rng_desc { void* out; int64_t n; int32_t kind; uint32_t thr; uint64_t stream_id; uint64_t offset; uint64_t ctr_mul; int32_t first_block; int32_t pad; } c1v_rng_desc;
 int c1v_philox_multi(const c1v_rng_desc* descs /*device*/, int32_t n_desc, int32_t total_blocks, uint64_t seed, const uint64_t* ctr, void* stream);
+
+/* Step prologue: the jobs of a step that depend on nothing but its inputs, in ONE launch -- c1v_philox_multi (n_rng > 0),
+ * c1v_pack_input or c1v_gather_input (at most one of pack / gather) and c1v_live_rows (live != NULL); every part is
+ * optional and computes exactly what the separate entry point computes.  No counterpart in the reference: Keras draws
+ * its dropout masks and builds batches op by op; here each separate launch cost 5-11 us of a ~260 us captured step. */
+typedef struct c1v_step_prologue_args {
+    const c1v_rng_desc* rng_descs; int32_t n_rng; int32_t rng_blocks; uint64_t seed; const uint64_t* ctr;
+    const c1v_pack_input_args* pack;
+    const c1v_gather_input_args* gather;
+    const c1v_live_rows_args* live;
+} c1v_step_prologue_args;
+int c1v_step_prologue(const c1v_step_prologue_args*, void* stream);
 
 /* ---- misc ---------------------------------------------------------------------------------------------------- */
 const char* c1v_last_error(void);

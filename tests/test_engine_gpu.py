@@ -126,6 +126,36 @@ def test_paired_backward_launch_is_bit_identical(name, dtype, monkeypatch):
 
 
 @pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_step_prologue_and_live_rows_are_bit_identical(dtype, monkeypatch):
+    """One-launch step prologue (rng + input pack + live-row table) and the compacted loss rows against the separate
+    launches over all rows: same draws (same Philox counters), same arithmetic per live row -> same loss and gradients."""
+    c = CASES['mid']
+    og, params, Wv, x, ids, eps, mask_e, mask_d = make_case(c)
+    assert (ids < 0).any() and (ids >= 0).any()
+    got = {}
+    for mode in (('1', '1'), ('0', '1'), ('0', '0')):
+        monkeypatch.setenv('C1V_PROLOGUE', mode[0])
+        monkeypatch.setenv('C1V_LIVE_ROWS', mode[1])
+        eng = build_engine(c, og, params, Wv, dtype)
+        eng.load_batch(x, ids)
+        eng._run(eng.train_ops(True))
+        torch.cuda.synchronize()
+        got[mode] = (eng.get_grads(), eng.loss(), eng.eps.cpu().numpy().copy(), eng.keep_e.cpu().numpy().copy())
+    ref = got[('0', '0')]
+    for mode in (('1', '1'), ('0', '1')):
+        np.testing.assert_array_equal(got[mode][2], ref[2])
+        np.testing.assert_array_equal(got[mode][3], ref[3])
+        if mode == ('1', '1'):                       # prologue on/off with the same loss path: to the bit
+            assert got[mode][1] == got[('0', '1')][1]
+            for k_, v in got[('0', '1')][0].items():
+                np.testing.assert_array_equal(got[mode][0][k_], v, err_msg=k_)
+        # compacted vs all rows: the vocabulary splits differ, so sums associate differently -- close, not identical
+        assert abs(got[mode][1] - ref[1]) < 1e-5 * max(1.0, abs(ref[1]))
+        for k_, v in ref[0].items():
+            assert rel_err(got[mode][0][k_], v) < (1e-4 if dtype == 'f32' else 2e-2), k_
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
 def test_nadam_trajectory_parity(dtype):
     """Five optimizer steps with fixed eps / masks: parameters and loss follow the oracle's Nadam(clipnorm=10)."""
     c = CASES['mid']
