@@ -115,7 +115,8 @@ class NadamArgs(C.Structure):
     _fields_ = [('p', C.c_void_p), ('g', C.c_void_p), ('m', C.c_void_p), ('v', C.c_void_p), ('n', C.c_int64),
                 ('grad_scale', C.c_float),
                 ('clipnorm', C.c_float), ('sched', C.c_void_p), ('beta1', C.c_float), ('beta2', C.c_float),
-                ('eps', C.c_float), ('norm_out', C.c_void_p)]
+                ('eps', C.c_float), ('norm_out', C.c_void_p), ('sq_partial', C.c_void_p), ('n_partial', C.c_int32),
+                ('sched_out7', C.c_void_p), ('ctr', C.c_void_p)]
 
 
 class RngDesc(C.Structure):
@@ -132,7 +133,7 @@ class LiveRowsArgs(C.Structure):
 class StepPrologueArgs(C.Structure):
     _fields_ = [('rng_descs', C.c_void_p), ('n_rng', C.c_int32), ('rng_blocks', C.c_int32), ('seed', C.c_uint64),
                 ('ctr', C.c_void_p), ('pack', C.POINTER(PackInputArgs)), ('gather', C.POINTER(GatherInputArgs)),
-                ('live', C.POINTER(LiveRowsArgs))]
+                ('live', C.POINTER(LiveRowsArgs)), ('nadam_state', C.c_void_p), ('sched', C.c_void_p)]
 
 
 class VocabArgmaxArgs(C.Structure):

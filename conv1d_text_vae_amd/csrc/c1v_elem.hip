@@ -358,14 +358,9 @@ extern "C" int c1v_sqnorm_partial(const float* x, int64_t n, float* sq_partial, 
 // Nadam (Keras 2.2 `Nadam.get_updates`, reference :1329) with global-norm clipping (`clip_norm`)
 // ------------------------------------------------------------------------------------------------------
 // state (device): [0] = iterations (as double), [1] = m_schedule, [2] = lr
-__global__ __launch_bounds__(256) void nadam_advance_kernel(double* __restrict__ state, float* __restrict__ sched,
-                                                            const float* __restrict__ sq_partial, int n_partial,
-                                                            uint64_t* __restrict__ ctr, double beta1, double beta2, double decay) {
-    __shared__ float red[4];
-    float sq = 0.f;
-    for (int i = threadIdx.x; i < n_partial; i += 256) sq += sq_partial[i];
-    sq = block_sum_256(sq, red);
-    if (threadIdx.x != 0) return;
+// schedule scalars of the NEXT update (one thread); sq < 0: leave sched[7] (the sum of squares) alone
+__device__ __forceinline__ void nadam_schedule(double* __restrict__ state, float* __restrict__ sched, float sq,
+                                               uint64_t* __restrict__ ctr, double beta1, double beta2, double decay) {
     const double t = state[0] + 1.0;
     const double mu_t = beta1 * (1.0 - 0.5 * pow(0.96, t * decay));
     const double mu_t1 = beta1 * (1.0 - 0.5 * pow(0.96, (t + 1.0) * decay));
@@ -378,10 +373,20 @@ __global__ __launch_bounds__(256) void nadam_advance_kernel(double* __restrict__
     sched[4] = (float)(1.0 - m_next);
     sched[5] = (float)(1.0 - pow(beta2, t));
     sched[6] = (float)t;
-    sched[7] = sq;
+    if (sq >= 0.f) sched[7] = sq;
     state[0] = t;
     state[1] = m_new;
     if (ctr) ctr[0] += 1;
+}
+__global__ __launch_bounds__(256) void nadam_advance_kernel(double* __restrict__ state, float* __restrict__ sched,
+                                                            const float* __restrict__ sq_partial, int n_partial,
+                                                            uint64_t* __restrict__ ctr, double beta1, double beta2, double decay) {
+    __shared__ float red[4];
+    float sq = 0.f;
+    for (int i = threadIdx.x; i < n_partial; i += 256) sq += sq_partial[i];
+    sq = block_sum_256(sq, red);
+    if (threadIdx.x != 0) return;
+    nadam_schedule(state, sched, sq, ctr, beta1, beta2, decay);
 }
 extern "C" int c1v_nadam_advance(double* state, float* sched, const float* sq_partial, int32_t n_partial, uint64_t* ctr, void* stream) {
     C1V_REQUIRE(state && sched && sq_partial && n_partial > 0, "nadam_advance: bad argument");
@@ -391,10 +396,25 @@ extern "C" int c1v_nadam_advance(double* state, float* sched, const float* sq_pa
 }
 
 __global__ __launch_bounds__(256) void nadam_kernel(c1v_nadam_args a) {
-    const float norm = sqrtf(a.sched[7]) * a.grad_scale;
+    // sum of squares of the gradient: from sched[7] (c1v_nadam_advance), or -- a.sq_partial given -- summed here by every
+    // block in the same fixed order (a few hundred values; saves the separate single-block launch before this kernel)
+    float sumsq;
+    if (a.sq_partial) {
+        __shared__ float red[4];
+        float sq = 0.f;
+        for (int i = threadIdx.x; i < a.n_partial; i += 256) sq += a.sq_partial[i];
+        sumsq = block_sum_256(sq, red);
+    } else {
+        sumsq = a.sched[7];
+    }
+    const float norm = sqrtf(sumsq) * a.grad_scale;
     float scale = a.grad_scale;
     if (a.clipnorm > 0.f && norm >= a.clipnorm) scale *= a.clipnorm / norm;
-    if (a.norm_out && blockIdx.x == 0 && threadIdx.x == 0) a.norm_out[0] = norm;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (a.norm_out) a.norm_out[0] = norm;
+        if (a.sq_partial) a.sched_out7[0] = sumsq;
+        if (a.ctr) a.ctr[0] += 1;                      // end of the step: the device-side RNG counter moves on
+    }
     const float lr = a.sched[0], mu_t = a.sched[1], mu_t1 = a.sched[2], om_new = a.sched[3], om_next = a.sched[4], ob2t = a.sched[5];
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * blockDim.x) {
         const float g = a.g[i] * scale;
@@ -412,6 +432,7 @@ __global__ __launch_bounds__(256) void nadam_kernel(c1v_nadam_args a) {
 extern "C" int c1v_nadam_step(const c1v_nadam_args* a, void* stream) {
     C1V_REQUIRE(a && a->p && a->g && a->m && a->v && a->sched, "nadam_step: null argument");
     C1V_REQUIRE(a->n > 0, "nadam_step: bad size");
+    C1V_REQUIRE(a->sq_partial == nullptr || (a->n_partial > 0 && a->sched_out7 != nullptr), "nadam_step: sq_partial needs n_partial and sched_out7");
     hipLaunchKernelGGL(nadam_kernel, dim3(grid_for(a->n)), dim3(256), 0, (hipStream_t)stream, *a);
     C1V_LAUNCH_CHECK();
     return 0;
@@ -584,11 +605,17 @@ struct PrologueDev {
     int in_kind, in_dtype, in_blocks;            // 0 none, 1 pack, 2 gather
     const float* src; int64_t ld; const int* in_ids; int T, C; c1v_seq dst;
     int live_blocks; const int* ids; int M, items, vocab_tiles, max_splits; int* pos; int* ctl;
+    int sched_blocks; double* nadam_state; float* sched;
 };
 __global__ __launch_bounds__(256) void step_prologue_kernel(const PrologueDev d) {
     int blk = (int)blockIdx.x;
     if (blk < d.live_blocks) { live_rows_body(d.ids, d.M, d.items, d.vocab_tiles, d.max_splits, d.pos, d.ctl); return; }
     blk -= d.live_blocks;
+    if (blk < d.sched_blocks) {                    // Nadam schedule scalars of this step's update (c1v_nadam_advance without the norm)
+        if (threadIdx.x == 0) nadam_schedule(d.nadam_state, d.sched, -1.0f, nullptr, 0.9, 0.999, 0.004);
+        return;
+    }
+    blk -= d.sched_blocks;
     if (blk < d.rng_blocks) { philox_multi_body(d.rng_descs, d.n_rng, d.seed, d.ctr, blk); return; }
     blk -= d.rng_blocks;
     if (d.in_kind == 1) {
@@ -629,7 +656,11 @@ extern "C" int c1v_step_prologue(const c1v_step_prologue_args* a, void* stream) 
         d.live_blocks = 1; d.ids = l->ids; d.M = l->M; d.items = l->items; d.vocab_tiles = l->vocab_tiles; d.max_splits = l->max_splits;
         d.pos = l->pos; d.ctl = l->ctl;
     }
-    const int total = d.live_blocks + d.rng_blocks + d.in_blocks;
+    if (a->nadam_state) {
+        C1V_REQUIRE(a->sched, "step_prologue: nadam_state needs sched");
+        d.sched_blocks = 1; d.nadam_state = a->nadam_state; d.sched = a->sched;
+    }
+    const int total = d.live_blocks + d.sched_blocks + d.rng_blocks + d.in_blocks;
     C1V_REQUIRE(total > 0, "step_prologue: nothing to do");
     hipLaunchKernelGGL(step_prologue_kernel, dim3((unsigned)total), dim3(256), 0, (hipStream_t)stream, d);
     C1V_LAUNCH_CHECK();

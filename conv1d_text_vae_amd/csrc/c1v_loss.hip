@@ -406,6 +406,7 @@ __global__ __launch_bounds__(256) void xent_finish_kernel(const float* __restric
     const float inv_q = 1.0f / qscale;
     const float inv_tau_eff = qscale * 0.6931471805599453f;     // 1/tau = qscale * ln 2
     float sumexp = 0.f;
+#pragma unroll 4
     for (int sp = 0; sp < splits; ++sp) sumexp += ut[((int64_t)sp * m_pad + cr) * kp + ones_col];
     float cnt = 0.f;
     for (int tt = lane; tt < T_len; tt += 64) cnt += ids[b * T_len + tt] >= 0 ? 1.f : 0.f;
@@ -434,13 +435,25 @@ __global__ __launch_bounds__(256) void xent_finish_kernel(const float* __restric
     const float rn = rnorm[m];
     const bool normal = rn < 0.99e6f;                           // sum y^2 >= 1e-12
     if (V <= 64 * UC) {
+        // slab loop outside, column loop (unrolled) inside: UC independent loads per slab are in flight together -- with the
+        // loops the other way round every load waited for the one before it (splits x UC serial round trips per row)
+#pragma unroll
+        for (int k = 0; k < UC; ++k) uu[k] = 0.f;
+#pragma unroll 2
+        for (int sp = 0; sp < splits; ++sp) {
+            const float* up = ut + ((int64_t)sp * m_pad + cr) * kp;
+#pragma unroll
+            for (int k = 0; k < UC; ++k) {
+                const int c = lane + 64 * k;
+                if (c < V) uu[k] += up[c];
+            }
+        }
 #pragma unroll
         for (int k = 0; k < UC; ++k) {
             const int c = lane + 64 * k;
-            uu[k] = 0.f; yy[k] = 0.f;
+            yy[k] = 0.f;
             if (c < V) {
-                float u = 0.f;
-                for (int sp = 0; sp < splits; ++sp) u += ut[((int64_t)sp * m_pad + cr) * kp + c];
+                const float u = uu[k];
                 uu[k] = coef * (u * inv_se - ElemTraits<T>::load(w, (int64_t)id * kp + c));
                 yy[k] = y ? y[(int64_t)m * ldy + c] * rn : ElemTraits<T>::load(yhat, (int64_t)cr * kp + c) * inv_q;
                 dot += uu[k] * yy[k];

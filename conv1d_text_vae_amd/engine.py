@@ -662,6 +662,12 @@ class VAEEngine:
         nad = L.NadamArgs(self.params.data_ptr(), self.grads.data_ptr(), self.nadam_m.data_ptr(), self.nadam_v.data_ptr(),
                           self.P, 1.0, CLIPNORM, self.sched.data_ptr(), 0.9, 0.999, 1e-7, self.norm_out.data_ptr())
         self.ops_update = ([sqnorm] if bucketed else []) + [advance, op('c1v_nadam_step', nad), self._pack_all]
+        # with the one-launch step prologue the schedule scalars are already in `sched` (computed at the start of the step,
+        # off the critical path); the Nadam kernel sums the gradient-norm partials itself and moves the RNG counter on
+        nad2 = L.NadamArgs(self.params.data_ptr(), self.grads.data_ptr(), self.nadam_m.data_ptr(), self.nadam_v.data_ptr(),
+                           self.P, 1.0, CLIPNORM, self.sched.data_ptr(), 0.9, 0.999, 1e-7, self.norm_out.data_ptr(),
+                           self.sq_partial.data_ptr(), n_partial, self.sched.data_ptr() + 4 * 7, self.step_ctr.data_ptr())
+        self.ops_update_fused = ([sqnorm] if bucketed else []) + [op('c1v_nadam_step', nad2), self._pack_all]
 
         # ---- RNG (device counter => replayable): eps + both dropout masks in ONE launch; the counter advances in
         # nadam_advance at the end of the step
@@ -783,9 +789,10 @@ class VAEEngine:
             self._run(main_ops)
         main.wait_stream(side)
 
-    def _prologue_op(self, with_rng: bool, from_ids: bool):
-        """One launch for the random draws, the encoder operand and the live-row table of a train step (c1v_step_prologue)."""
-        key = (with_rng, from_ids)
+    def _prologue_op(self, with_rng: bool, from_ids: bool, advance: bool = False):
+        """One launch for the random draws, the encoder operand, the live-row table and (advance: the step ends in an
+        optimizer update) the Nadam schedule scalars of a train step (c1v_step_prologue)."""
+        key = (with_rng, from_ids, advance)
         if key not in self._prologue_cache:
             if from_ids and self.ops_gather_in is None:
                 raise L.C1VError('from_ids=True needs set_input_table() first')
@@ -793,19 +800,28 @@ class VAEEngine:
                                    self._rng_blocks if with_rng else 0, self.seed, self.step_ctr.data_ptr(),
                                    None if from_ids else C.pointer(self._pack_in_args),
                                    C.pointer(self._gather_args) if from_ids else None,
-                                   C.pointer(self._live_args) if self.compact else None)
+                                   C.pointer(self._live_args) if self.compact else None,
+                                   self.nadam_state.data_ptr() if advance else None, self.sched.data_ptr() if advance else None)
             self._prologue_cache[key] = self._op('c1v_step_prologue', a)
         return self._prologue_cache[key]
 
-    def forward_ops(self, with_rng: bool, from_ids: bool = False):
-        if os.environ.get('C1V_PROLOGUE', '1') == '1':
-            return [self._prologue_op(with_rng, from_ids)] + self.ops_enc_train + self.ops_lat_train + self.ops_dec + \
+    def _fused_prologue(self) -> bool:
+        return os.environ.get('C1V_PROLOGUE', '1') == '1'
+
+    def update_ops(self):
+        """Optimizer update of a step whose forward_ops were built with advance=True."""
+        return self.ops_update_fused if self._fused_prologue() else self.ops_update
+
+    def forward_ops(self, with_rng: bool, from_ids: bool = False, advance: bool = False):
+        """advance: the step ends in update_ops() (the fused prologue then also prepares the Nadam schedule)."""
+        if self._fused_prologue():
+            return [self._prologue_op(with_rng, from_ids, advance)] + self.ops_enc_train + self.ops_lat_train + self.ops_dec + \
                 self.ops_loss_train_core
         return (self.ops_rng if with_rng else []) + self._in_ops(from_ids) + self.ops_enc_train + self.ops_lat_train + \
             self.ops_dec + self.ops_loss_train
 
-    def train_ops(self, with_rng: bool, from_ids: bool = False):
-        return self.forward_ops(with_rng, from_ids) + [self._run_backward] + self.ops_finalize
+    def train_ops(self, with_rng: bool, from_ids: bool = False, advance: bool = False):
+        return self.forward_ops(with_rng, from_ids, advance) + [self._run_backward] + self.ops_finalize
 
     def train_step(self, use_graph: bool = True, fixed_rng: bool = False, all_reduce=None, from_ids: bool = False):
         """One fit step on the batch resident in x_in / ids_in: forward, loss, backward, clip, Nadam, operand refresh.
@@ -829,7 +845,7 @@ class VAEEngine:
                 self._run(ops)
 
         if self.world == 1 and not self.force_bucketed:
-            go('train', self.train_ops(not fixed_rng, from_ids) + self.ops_update)
+            go('train', self.train_ops(not fixed_rng, from_ids, True) + self.update_ops())
             return
         if all_reduce is None:
             raise L.C1VError('world_size > 1 needs an all_reduce callable')
@@ -852,9 +868,9 @@ class VAEEngine:
                         w.wait()
                 del waits[:]
             try:
-                go('train_dp1', self.forward_ops(not fixed_rng, from_ids) + [lambda: self._run_backward(0, k)] +
+                go('train_dp1', self.forward_ops(not fixed_rng, from_ids, True) + [lambda: self._run_backward(0, k)] +
                    self.ops_finalize_dec + [ar_dec, lambda: self._run_backward(k, None)] + self.ops_finalize_enc +
-                   [ar_enc, join] + self.ops_update)
+                   [ar_enc, join] + self.update_ops())
                 return
             except Exception as exc:                                   # noqa: BLE001 - capture of a collective refused
                 import sys
@@ -864,14 +880,14 @@ class VAEEngine:
                 self._graphs.pop('train_dp1' + ('_fixed' if fixed_rng else '') + sfx, None)
                 if getattr(self, '_saved_for_capture', None) is not None:
                     self._restore_state(self._saved_for_capture)
-        go('train_a1', self.forward_ops(not fixed_rng, from_ids) + [lambda: self._run_backward(0, k)] + self.ops_finalize_dec)
+        go('train_a1', self.forward_ops(not fixed_rng, from_ids, True) + [lambda: self._run_backward(0, k)] + self.ops_finalize_dec)
         w1 = all_reduce(self.grads[self.dec_range[0]:self.dec_range[1]])
         go('train_a2', [lambda: self._run_backward(k, None)] + self.ops_finalize_enc)
         w2 = all_reduce(self.grads[self.enc_range[0]:self.enc_range[1]])
         for w in (w1, w2):
             if w is not None and hasattr(w, 'wait'):
                 w.wait()
-        go('train_b', self.ops_update)
+        go('train_b', self.update_ops())
 
     def eval_step(self, use_graph: bool = True, fixed_rng: bool = False, from_ids: bool = False):
         """Validation loss of the resident batch (dropout off, eps still sampled -- Keras test phase of FullVAE)."""

@@ -291,6 +291,10 @@ typedef struct c1v_nadam_args {
     const float* sched;        /* DEVICE [8]: lr, mu_t, mu_t1, 1-m_schedule_new, 1-m_schedule_next, 1-beta2^t, t, sum of squares of the gradient */
     float beta1, beta2, eps;
     float* norm_out;           /* optional [1] */
+    const float* sq_partial;   /* optional: sum of squares = sum of sq_partial[0..n_partial) computed inside this kernel instead */
+    int32_t n_partial;         /*           of sched[7] (sched then only needs the schedule scalars, see c1v_step_prologue) */
+    float* sched_out7;         /*           required with sq_partial: receives that sum (normally &sched[7]) */
+    uint64_t* ctr;             /* optional: RNG step counter, incremented once (c1v_nadam_advance does it otherwise) */
 } c1v_nadam_args;
 int c1v_nadam_step(const c1v_nadam_args*, void* stream);
 /* state (DEVICE double[3]) = {iterations, m_schedule, lr}; writes the scalars of the NEXT step into sched[8] (sched[7] =
@@ -355,6 +359,9 @@ typedef struct c1v_step_prologue_args {
     const c1v_pack_input_args* pack;
     const c1v_gather_input_args* gather;
     const c1v_live_rows_args* live;
+    double* nadam_state; float* sched;   /* optional: the schedule scalars of this step's Nadam update (c1v_nadam_advance
+                                            without the gradient norm and without the RNG-counter increment; pair it with
+                                            c1v_nadam_step's sq_partial / ctr fields) */
 } c1v_step_prologue_args;
 int c1v_step_prologue(const c1v_step_prologue_args*, void* stream);
 

@@ -311,7 +311,7 @@ def test_two_rank_bucketed_step_equals_single_rank_step():
             return ar
         k = ranks[0].n_dec_stages
         for e in ranks:
-            e._run(e.forward_ops(False) + [lambda e=e: e._run_backward(0, k)] + e.ops_finalize_dec)
+            e._run(e.forward_ops(False, advance=True) + [lambda e=e: e._run_backward(0, k)] + e.ops_finalize_dec)
         lo, hi = ranks[0].dec_range
         tot = ranks[0].grads[lo:hi] + ranks[1].grads[lo:hi]
         for e in ranks:
@@ -323,7 +323,7 @@ def test_two_rank_bucketed_step_equals_single_rank_step():
         for e in ranks:
             e.grads[lo:hi].copy_(tot)
         for e in ranks:
-            e._run(e.ops_update)
+            e._run(e.update_ops())
         torch.cuda.synchronize()
         np.testing.assert_allclose(ranks[0].grads.cpu().numpy(), full.grads.cpu().numpy(), rtol=2e-4, atol=1e-7)
     w_full, w0, w1 = full.get_weights(), ranks[0].get_weights(), ranks[1].get_weights()
