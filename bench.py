@@ -154,7 +154,9 @@ def main():
     if args.traffic is None:
         # HBM bytes per launch of the dominant kernel come from SEPARATE rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE;
         # gfx950 correction: FETCH_SIZE counts half of a wide streaming read) whose summary is committed under profiles/
-        pmc = os.path.join(ROOT, 'profiles', 'r01_c_pmc_vocab_stream.json')
+        import glob
+        found = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_vocab_stream.json')))
+        pmc = found[-1] if found else ''
         if os.path.isfile(pmc):
             with open(pmc) as fp:
                 c = json.load(fp)['per_launch_avg']
