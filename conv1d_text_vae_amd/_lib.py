@@ -133,7 +133,8 @@ class LiveRowsArgs(C.Structure):
 class StepPrologueArgs(C.Structure):
     _fields_ = [('rng_descs', C.c_void_p), ('n_rng', C.c_int32), ('rng_blocks', C.c_int32), ('seed', C.c_uint64),
                 ('ctr', C.c_void_p), ('pack', C.POINTER(PackInputArgs)), ('gather', C.POINTER(GatherInputArgs)),
-                ('live', C.POINTER(LiveRowsArgs)), ('nadam_state', C.c_void_p), ('sched', C.c_void_p)]
+                ('live', C.POINTER(LiveRowsArgs)), ('nadam_state', C.c_void_p), ('sched', C.c_void_p),
+                ('pack_descs', C.c_void_p), ('n_pack', C.c_int32), ('pack_blocks', C.c_int32)]
 
 
 class VocabArgmaxArgs(C.Structure):

@@ -125,16 +125,16 @@ extern "C" int c1v_gather_input(const c1v_gather_input_args* a, void* stream) {
 // ------------------------------------------------------------------------------------------------------
 // weight operand copies (descriptor table on the device; blockIdx.y = descriptor)
 // ------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void pack_weights_kernel(const c1v_pack_desc* __restrict__ descs, int n_desc) {
+__device__ __forceinline__ void pack_weights_body(const c1v_pack_desc* __restrict__ descs, int n_desc, int blk) {
     // One block = one 32(c) x 32(n) tile of one tap of one descriptor, transposed through LDS so that BOTH the fp32 read
     // (along whichever of n / c is contiguous in the Keras layout) and the operand write (along c) are whole row
     // segments.  Blocks are dealt to descriptors by `first_block`; within a descriptor the tile index enumerates
     // (tap, c tile, n tile).
     __shared__ float tile[32][33];
-    const int di = find_desc(descs, n_desc, (int)blockIdx.x);
+    const int di = find_desc(descs, n_desc, blk);
     const c1v_pack_desc d = descs[di];
     const int tc = (d.c_count + 31) >> 5, tn = (d.n_count + 31) >> 5;
-    int bi = (int)blockIdx.x - d.first_block;
+    int bi = blk - d.first_block;
     const int tn_i = bi % tn; bi /= tn;
     const int tc_i = bi % tc;
     const int tap = bi / tc;
@@ -164,6 +164,10 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const c1v_pack_desc* 
         const int n = n0 + ty + 8 * k, c = c0 + tx;
         if (c < d.c_count && n < d.n_count) store_any(d.dst, d.dtype, (int64_t)n * d.ldk + (int64_t)tp * d.cp + c, tile[tx][ty + 8 * k]);
     }
+}
+
+__global__ __launch_bounds__(256) void pack_weights_kernel(const c1v_pack_desc* __restrict__ descs, int n_desc) {
+    pack_weights_body(descs, n_desc, (int)blockIdx.x);
 }
 
 extern "C" int c1v_pack_weights(const c1v_pack_desc* descs, int32_t n_desc, int32_t total_blocks, void* stream) {
@@ -606,6 +610,7 @@ struct PrologueDev {
     const float* src; int64_t ld; const int* in_ids; int T, C; c1v_seq dst;
     int live_blocks; const int* ids; int M, items, vocab_tiles, max_splits; int* pos; int* ctl;
     int sched_blocks; double* nadam_state; float* sched;
+    int pack_blocks; const c1v_pack_desc* pack_descs; int n_pack;
 };
 __global__ __launch_bounds__(256) void step_prologue_kernel(const PrologueDev d) {
     int blk = (int)blockIdx.x;
@@ -618,6 +623,8 @@ __global__ __launch_bounds__(256) void step_prologue_kernel(const PrologueDev d)
     blk -= d.sched_blocks;
     if (blk < d.rng_blocks) { philox_multi_body(d.rng_descs, d.n_rng, d.seed, d.ctr, blk); return; }
     blk -= d.rng_blocks;
+    if (blk < d.pack_blocks) { pack_weights_body(d.pack_descs, d.n_pack, blk); return; }
+    blk -= d.pack_blocks;
     if (d.in_kind == 1) {
         if (d.in_dtype == C1V_F32) pack_input_body<float>(d.src, d.T, d.C, d.dst, blk, d.in_blocks);
         else pack_input_body<bf16_raw>(d.src, d.T, d.C, d.dst, blk, d.in_blocks);
@@ -660,7 +667,11 @@ extern "C" int c1v_step_prologue(const c1v_step_prologue_args* a, void* stream) 
         C1V_REQUIRE(a->sched, "step_prologue: nadam_state needs sched");
         d.sched_blocks = 1; d.nadam_state = a->nadam_state; d.sched = a->sched;
     }
-    const int total = d.live_blocks + d.sched_blocks + d.rng_blocks + d.in_blocks;
+    if (a->n_pack > 0) {
+        C1V_REQUIRE(a->pack_descs && a->pack_blocks > 0, "step_prologue: bad weight-pack table");
+        d.pack_blocks = a->pack_blocks; d.pack_descs = a->pack_descs; d.n_pack = a->n_pack;
+    }
+    const int total = d.live_blocks + d.sched_blocks + d.rng_blocks + d.pack_blocks + d.in_blocks;
     C1V_REQUIRE(total > 0, "step_prologue: nothing to do");
     hipLaunchKernelGGL(step_prologue_kernel, dim3((unsigned)total), dim3(256), 0, (hipStream_t)stream, d);
     C1V_LAUNCH_CHECK();

@@ -12,6 +12,7 @@
 // U^T the softmax denominator for free.  Modes: ACCUM (training: U^T), SUMEXP (validation: only the denominator),
 // ARGMAX (predict: fused per-row arg-max, lowest index wins ties).
 #include "c1v_common.h"
+#include <stdlib.h>
 #include "c1v_lossred.h"
 
 // ------------------------------------------------------------------------------------------------------
@@ -405,6 +406,128 @@ __global__ __launch_bounds__(256) void xent_finish_kernel(const float* __restric
     }
     const float inv_q = 1.0f / qscale;
     const float inv_tau_eff = qscale * 0.6931471805599453f;     // 1/tau = qscale * ln 2
+    // Training row with a target, rows of at most 512 columns (the common case): every lane owns 4-column chunks
+    // (columns 4 (lane + 64 q) ..) and moves them as 8- / 16-byte words.  The kernel is bound by the NUMBER of memory
+    // instructions a CU can issue (measured: its time scales with 1/occupancy and one-column-per-lane loads need ~60
+    // instructions per row); chunks need ~20, and the softmax denominator comes with the chunk that holds `ones_col`.
+    constexpr int NCH = 2;
+    if (mask && dy.data != nullptr && V <= 256 * NCH && (kp & 3) == 0 && kp <= 256 * NCH && ones_col >= V &&
+        ((((uintptr_t)ut) & 15) == 0) && ((((uintptr_t)w) | ((uintptr_t)yhat)) & 15) == 0) {
+        float us[NCH][4], wv[NCH][4], yh[NCH][4], yv[NCH][4];
+#pragma unroll
+        for (int q = 0; q < NCH; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { us[q][e] = 0.f; wv[q][e] = 0.f; yh[q][e] = 0.f; yv[q][e] = 0.f; }
+        // Loads are UNCONDITIONAL (the chunk index is clamped into the row and the value masked afterwards): a load under
+        // `if (column < width)` compiles to a branch with its own s_waitcnt, i.e. one full memory round trip per load
+        // (that is what the one-column-per-lane path below does: ~60 dependent round trips per row).
+        int cc[NCH];
+        bool in_kp[NCH];
+#pragma unroll
+        for (int q = 0; q < NCH; ++q) { const int c0 = 4 * (lane + 64 * q); in_kp[q] = c0 < kp; cc[q] = in_kp[q] ? c0 : kp - 4; }
+#pragma unroll 2
+        for (int sp = 0; sp < splits; ++sp) {
+            const float* up = ut + ((int64_t)sp * m_pad + cr) * kp;
+#pragma unroll
+            for (int q = 0; q < NCH; ++q) {
+                const float4 v = *(const float4*)(up + cc[q]);
+                us[q][0] += v.x; us[q][1] += v.y; us[q][2] += v.z; us[q][3] += v.w;
+            }
+        }
+        float cnt1 = 0.f;
+        for (int tt = lane; tt < T_len; tt += 64) cnt1 += ids[b * T_len + tt] >= 0 ? 1.f : 0.f;
+        const float rn1 = rnorm[m];
+        const bool y2 = y != nullptr && ((((uintptr_t)y) & 7) == 0) && (ldy & 1) == 0 && (V & 1) == 0 && V >= 4;
+#pragma unroll
+        for (int q = 0; q < NCH; ++q) {
+            if constexpr (sizeof(T) == 2) {
+                const uint2 a = *(const uint2*)((const bf16_raw*)w + (int64_t)id * kp + cc[q]);
+                const uint2 h2 = *(const uint2*)((const bf16_raw*)yhat + (int64_t)cr * kp + cc[q]);
+                wv[q][0] = __uint_as_float(a.x << 16); wv[q][1] = __uint_as_float(a.x & 0xFFFF0000u);
+                wv[q][2] = __uint_as_float(a.y << 16); wv[q][3] = __uint_as_float(a.y & 0xFFFF0000u);
+                yh[q][0] = __uint_as_float(h2.x << 16); yh[q][1] = __uint_as_float(h2.x & 0xFFFF0000u);
+                yh[q][2] = __uint_as_float(h2.y << 16); yh[q][3] = __uint_as_float(h2.y & 0xFFFF0000u);
+            } else {
+                const float4 a = *(const float4*)((const float*)w + (int64_t)id * kp + cc[q]);
+                const float4 h4 = *(const float4*)((const float*)yhat + (int64_t)cr * kp + cc[q]);
+                wv[q][0] = a.x; wv[q][1] = a.y; wv[q][2] = a.z; wv[q][3] = a.w;
+                yh[q][0] = h4.x; yh[q][1] = h4.y; yh[q][2] = h4.z; yh[q][3] = h4.w;
+            }
+            if (y2) {
+                // the chunk may hang over the end of the (unpadded) row: read the last whole chunk instead and shift
+                const int c0 = 4 * (lane + 64 * q);
+                const int cy = c0 + 3 < V ? c0 : V - 4;
+                const float* yr = y + (int64_t)m * ldy + cy;
+                const float2 a = *(const float2*)yr, b2 = *(const float2*)(yr + 2);
+                const float t4[4] = {a.x, a.y, b2.x, b2.y};
+                const int sh = c0 - cy;                       // 0, or 2 for the chunk that straddles the end (V even)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) yv[q][e] = (e + sh < 4) ? (sh == 0 ? t4[e] : t4[(e + 2) & 3]) : 0.f;
+            } else if (y != nullptr) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int c = 4 * (lane + 64 * q) + e;
+                    yv[q][e] = y[(int64_t)m * ldy + (c < V ? c : V - 1)];
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < NCH; ++q)
+            if (!in_kp[q]) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { us[q][e] = 0.f; wv[q][e] = 0.f; yh[q][e] = 0.f; }
+            }
+        // softmax denominator: element `ones_col` of the summed row (w carries 1.0 in that column)
+        const int ocj = ones_col >> 2, oce = ones_col & 3;
+        float se = 0.f;
+#pragma unroll
+        for (int q = 0; q < NCH; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if ((ocj >> 6) == q && oce == e) se = __shfl(us[q][e], ocj & 63, 64);
+        float st1 = 0.f;
+#pragma unroll
+        for (int q = 0; q < NCH; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (4 * (lane + 64 * q) + e < V) st1 += yh[q][e] * wv[q][e];
+        cnt1 = wave_sum(cnt1);
+        st1 = wave_sum(st1);
+        const float p1 = exp2f(st1) / se;
+        const bool live1 = p1 > 1e-7f && p1 < (1.0f - 1e-7f);
+        if (lane == 0) xent_rows[m] = -logf(fminf(fmaxf(p1, 1e-7f), 1.0f - 1e-7f));
+        const int64_t drow1 = (int64_t)b * dy.bstride + (int64_t)(dy.off + t) * dy.cp;
+        const float coef1 = live1 ? inv_tau_eff / (cnt1 * (float)B_global) : 0.0f;     // clipped: zero gradient
+        const float inv_se1 = 1.0f / se;
+        const bool normal1 = rn1 < 0.99e6f;                      // sum y^2 >= 1e-12
+        float dot1 = 0.f;
+#pragma unroll
+        for (int q = 0; q < NCH; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const bool in = 4 * (lane + 64 * q) + e < V;
+                us[q][e] = in ? coef1 * (us[q][e] * inv_se1 - wv[q][e]) : 0.f;
+                yv[q][e] = in ? (y ? yv[q][e] * rn1 : yh[q][e] * inv_q) : 0.f;
+                dot1 += us[q][e] * yv[q][e];
+            }
+        dot1 = wave_sum(dot1);
+        const bool st8 = dy.dtype == C1V_BF16 && ((((uintptr_t)dy.data) & 7) == 0) && (dy.cp & 3) == 0 && (dy.bstride & 3) == 0;
+#pragma unroll
+        for (int q = 0; q < NCH; ++q) {
+            const int c0 = 4 * (lane + 64 * q);
+            if (c0 >= V) continue;
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = coef1 == 0.0f ? 0.0f : (normal1 ? (us[q][e] - yv[q][e] * dot1) * rn1 : us[q][e] * rn1);
+            if (st8 && c0 + 3 < V) {
+                *(uint2*)((bf16_raw*)dy.data + drow1 + c0) = make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (c0 + e < V) store_any(dy.data, dy.dtype, drow1 + c0 + e, o[e]);
+            }
+        }
+        return;
+    }
     float sumexp = 0.f;
 #pragma unroll 4
     for (int sp = 0; sp < splits; ++sp) sumexp += ut[((int64_t)sp * m_pad + cr) * kp + ones_col];
@@ -690,7 +813,7 @@ extern "C" int c1v_cos_softmax_finish(const c1v_xent_finish_args* a, void* strea
     C1V_REQUIRE(a->m_pad >= (int)(c1v_cdiv((int64_t)a->B * a->T, 32) * 32), "cos_softmax_finish: m_pad too small");
     C1V_REQUIRE(a->dy.data == nullptr || (a->dy.cp >= a->V && a->dy.len >= a->T), "cos_softmax_finish: dy buffer too small");
     const int M = a->B * a->T;
-    const size_t lds = 0;
+    static const size_t lds = getenv("C1V_FINISH_LDS") ? (size_t)atoi(getenv("C1V_FINISH_LDS")) : 0;   // diagnostic: caps the resident waves per CU
     dim3 grid((unsigned)c1v_cdiv(M, 4));
     if (a->dtype == C1V_F32)
         hipLaunchKernelGGL(xent_finish_kernel<float>, grid, dim3(256), lds, (hipStream_t)stream, a->ut, a->splits, a->kp, a->m_pad, a->ones_col,

@@ -332,8 +332,11 @@ class VAEEngine:
         self.n_pack = len(descs)
         self.pack_blocks = nblk[0]
 
+        self._wop_stale = False
+
         def pack_all():
             L.call('c1v_pack_weights', self.pack_descs.data_ptr(), self.n_pack, self.pack_blocks, self._stream())
+            self._wop_stale = False
         self._pack_all = pack_all
         pack_all()
 
@@ -667,7 +670,11 @@ class VAEEngine:
         nad2 = L.NadamArgs(self.params.data_ptr(), self.grads.data_ptr(), self.nadam_m.data_ptr(), self.nadam_v.data_ptr(),
                            self.P, 1.0, CLIPNORM, self.sched.data_ptr(), 0.9, 0.999, 1e-7, self.norm_out.data_ptr(),
                            self.sq_partial.data_ptr(), n_partial, self.sched.data_ptr() + 4 * 7, self.step_ctr.data_ptr())
-        self.ops_update_fused = ([sqnorm] if bucketed else []) + [op('c1v_nadam_step', nad2), self._pack_all]
+        # ... and the operand copies of the updated weights are refreshed by the NEXT step's prologue (every fused prologue
+        # packs); the inference entry points call _ensure_packed() first
+        def mark_stale():
+            self._wop_stale = True
+        self.ops_update_fused = ([sqnorm] if bucketed else []) + [op('c1v_nadam_step', nad2), mark_stale]
 
         # ---- RNG (device counter => replayable): eps + both dropout masks in ONE launch; the counter advances in
         # nadam_advance at the end of the step
@@ -801,12 +808,18 @@ class VAEEngine:
                                    None if from_ids else C.pointer(self._pack_in_args),
                                    C.pointer(self._gather_args) if from_ids else None,
                                    C.pointer(self._live_args) if self.compact else None,
-                                   self.nadam_state.data_ptr() if advance else None, self.sched.data_ptr() if advance else None)
+                                   self.nadam_state.data_ptr() if advance else None, self.sched.data_ptr() if advance else None,
+                                   self.pack_descs.data_ptr(), self.n_pack, self.pack_blocks)
             self._prologue_cache[key] = self._op('c1v_step_prologue', a)
         return self._prologue_cache[key]
 
     def _fused_prologue(self) -> bool:
         return os.environ.get('C1V_PROLOGUE', '1') == '1'
+
+    def _ensure_packed(self):
+        """Operand copies of the weights are refreshed lazily after a fused-prologue train step (see ops_update_fused)."""
+        if self._wop_stale:
+            self._pack_all()
 
     def update_ops(self):
         """Optimizer update of a step whose forward_ops were built with advance=True."""
@@ -844,8 +857,11 @@ class VAEEngine:
             else:
                 self._run(ops)
 
+        # (graph replays do not run the Python-side `mark_stale` op of update_ops(): set the flag here)
+        stale_after = self._fused_prologue()
         if self.world == 1 and not self.force_bucketed:
             go('train', self.train_ops(not fixed_rng, from_ids, True) + self.update_ops())
+            self._wop_stale = stale_after
             return
         if all_reduce is None:
             raise L.C1VError('world_size > 1 needs an all_reduce callable')
@@ -871,6 +887,7 @@ class VAEEngine:
                 go('train_dp1', self.forward_ops(not fixed_rng, from_ids, True) + [lambda: self._run_backward(0, k)] +
                    self.ops_finalize_dec + [ar_dec, lambda: self._run_backward(k, None)] + self.ops_finalize_enc +
                    [ar_enc, join] + self.update_ops())
+                self._wop_stale = stale_after
                 return
             except Exception as exc:                                   # noqa: BLE001 - capture of a collective refused
                 import sys
@@ -888,9 +905,11 @@ class VAEEngine:
             if w is not None and hasattr(w, 'wait'):
                 w.wait()
         go('train_b', self.update_ops())
+        self._wop_stale = stale_after
 
     def eval_step(self, use_graph: bool = True, fixed_rng: bool = False, from_ids: bool = False):
         """Validation loss of the resident batch (dropout off, eps still sampled -- Keras test phase of FullVAE)."""
+        self._ensure_packed()
         ops = ([] if fixed_rng else self.ops_rng_eval) + self._in_ops(from_ids) + self.ops_enc_infer + self.ops_lat_eval + \
             self.ops_dec + self.ops_loss_eval
         if use_graph:
@@ -901,6 +920,7 @@ class VAEEngine:
     def sample_reconstruct(self, use_graph: bool = True, from_ids: bool = False, postprocess: bool = True) -> torch.Tensor:
         """FullVAE.predict_on_batch (:1462-1464): dropout off, z SAMPLED (the stage-2 generator trains on these), then
         optionally postprocess_reconstructed_word_vectors."""
+        self._ensure_packed()
         ops = self.ops_rng_eval + self._in_ops(from_ids) + self.ops_enc_infer + self.ops_lat_eval + self.ops_dec + \
             (self.ops_post if postprocess else [])
         if use_graph:
@@ -914,6 +934,7 @@ class VAEEngine:
 
     def encode(self, use_graph: bool = True) -> torch.Tensor:
         """vae_encoder_.predict_on_batch (:404): z_mean of the resident batch, [B, latent] fp32 (device)."""
+        self._ensure_packed()
         ops = self.ops_pack_in + self.ops_enc_infer
         if use_graph:
             self._graph('encode', ops)
@@ -923,6 +944,7 @@ class VAEEngine:
 
     def reconstruct(self, use_graph: bool = True, postprocess: bool = True) -> torch.Tensor:
         """vae_decoder_(vae_encoder_(x)) (:440) and, optionally, postprocess_reconstructed_word_vectors (:439)."""
+        self._ensure_packed()
         ops = self.ops_pack_in + self.ops_enc_infer + self.ops_lat_infer + self.ops_dec + (self.ops_post if postprocess else [])
         if use_graph:
             self._graph('recon_post' if postprocess else 'recon', ops)

@@ -362,6 +362,9 @@ typedef struct c1v_step_prologue_args {
     double* nadam_state; float* sched;   /* optional: the schedule scalars of this step's Nadam update (c1v_nadam_advance
                                             without the gradient norm and without the RNG-counter increment; pair it with
                                             c1v_nadam_step's sq_partial / ctr fields) */
+    const c1v_pack_desc* pack_descs; int32_t n_pack; int32_t pack_blocks;   /* optional: c1v_pack_weights (the operand copies
+                                            of the weights the PREVIOUS step updated: refreshed here, beside the other jobs,
+                                            instead of in a launch of their own at the end of that step) */
 } c1v_step_prologue_args;
 int c1v_step_prologue(const c1v_step_prologue_args*, void* stream);
 
