@@ -425,50 +425,82 @@ __global__ __launch_bounds__(256) void xent_finish_kernel(const float* __restric
         bool in_kp[NCH];
 #pragma unroll
         for (int q = 0; q < NCH; ++q) { const int c0 = 4 * (lane + 64 * q); in_kp[q] = c0 < kp; cc[q] = in_kp[q] ? c0 : kp - 4; }
-#pragma unroll 2
-        for (int sp = 0; sp < splits; ++sp) {
-            const float* up = ut + ((int64_t)sp * m_pad + cr) * kp;
-#pragma unroll
-            for (int q = 0; q < NCH; ++q) {
-                const float4 v = *(const float4*)(up + cc[q]);
-                us[q][0] += v.x; us[q][1] += v.y; us[q][2] += v.z; us[q][3] += v.w;
-            }
-        }
-        float cnt1 = 0.f;
-        for (int tt = lane; tt < T_len; tt += 64) cnt1 += ids[b * T_len + tt] >= 0 ? 1.f : 0.f;
+        // (the first 64 steps of the sample's target count ride in the same batch of requests)
+        const int tl = lane < T_len ? lane : T_len - 1;
+        const int id_l = ids[b * T_len + tl];
         const float rn1 = rnorm[m];
         const bool y2 = y != nullptr && ((((uintptr_t)y) & 7) == 0) && (ldy & 1) == 0 && (V & 1) == 0 && V >= 4;
+        // raw words only: nothing is converted (= waited for) until the slab requests below are out as well
+        uint4 wraw[NCH], hraw[NCH];
+        float2 ya[NCH], yb[NCH];
+        float ye[NCH][4];
 #pragma unroll
         for (int q = 0; q < NCH; ++q) {
+            wraw[q] = make_uint4(0u, 0u, 0u, 0u); hraw[q] = wraw[q];
+            ya[q] = make_float2(0.f, 0.f); yb[q] = ya[q];
             if constexpr (sizeof(T) == 2) {
                 const uint2 a = *(const uint2*)((const bf16_raw*)w + (int64_t)id * kp + cc[q]);
                 const uint2 h2 = *(const uint2*)((const bf16_raw*)yhat + (int64_t)cr * kp + cc[q]);
-                wv[q][0] = __uint_as_float(a.x << 16); wv[q][1] = __uint_as_float(a.x & 0xFFFF0000u);
-                wv[q][2] = __uint_as_float(a.y << 16); wv[q][3] = __uint_as_float(a.y & 0xFFFF0000u);
-                yh[q][0] = __uint_as_float(h2.x << 16); yh[q][1] = __uint_as_float(h2.x & 0xFFFF0000u);
-                yh[q][2] = __uint_as_float(h2.y << 16); yh[q][3] = __uint_as_float(h2.y & 0xFFFF0000u);
+                wraw[q].x = a.x; wraw[q].y = a.y; hraw[q].x = h2.x; hraw[q].y = h2.y;
             } else {
-                const float4 a = *(const float4*)((const float*)w + (int64_t)id * kp + cc[q]);
-                const float4 h4 = *(const float4*)((const float*)yhat + (int64_t)cr * kp + cc[q]);
-                wv[q][0] = a.x; wv[q][1] = a.y; wv[q][2] = a.z; wv[q][3] = a.w;
-                yh[q][0] = h4.x; yh[q][1] = h4.y; yh[q][2] = h4.z; yh[q][3] = h4.w;
+                wraw[q] = *(const uint4*)((const float*)w + (int64_t)id * kp + cc[q]);
+                hraw[q] = *(const uint4*)((const float*)yhat + (int64_t)cr * kp + cc[q]);
             }
             if (y2) {
                 // the chunk may hang over the end of the (unpadded) row: read the last whole chunk instead and shift
                 const int c0 = 4 * (lane + 64 * q);
                 const int cy = c0 + 3 < V ? c0 : V - 4;
                 const float* yr = y + (int64_t)m * ldy + cy;
-                const float2 a = *(const float2*)yr, b2 = *(const float2*)(yr + 2);
-                const float t4[4] = {a.x, a.y, b2.x, b2.y};
-                const int sh = c0 - cy;                       // 0, or 2 for the chunk that straddles the end (V even)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) yv[q][e] = (e + sh < 4) ? (sh == 0 ? t4[e] : t4[(e + 2) & 3]) : 0.f;
+                ya[q] = *(const float2*)yr; yb[q] = *(const float2*)(yr + 2);
             } else if (y != nullptr) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int c = 4 * (lane + 64 * q) + e;
-                    yv[q][e] = y[(int64_t)m * ldy + (c < V ? c : V - 1)];
+                    ye[q][e] = y[(int64_t)m * ldy + (c < V ? c : V - 1)];
                 }
+            }
+        }
+        // partial sums of the vocabulary splits, four slabs (8 requests) per round, in slab order
+        for (int sp0 = 0; sp0 < splits; sp0 += 4) {
+            float4 v[4][NCH];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int sp = sp0 + i < splits ? sp0 + i : splits - 1;
+                const float* up = ut + ((int64_t)sp * m_pad + cr) * kp;
+#pragma unroll
+                for (int q = 0; q < NCH; ++q) v[i][q] = *(const float4*)(up + cc[q]);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (sp0 + i < splits) {
+#pragma unroll
+                    for (int q = 0; q < NCH; ++q) { us[q][0] += v[i][q].x; us[q][1] += v[i][q].y; us[q][2] += v[i][q].z; us[q][3] += v[i][q].w; }
+                }
+        }
+        float cnt1 = (lane < T_len && id_l >= 0) ? 1.f : 0.f;
+        for (int tt = lane + 64; tt < T_len; tt += 64) cnt1 += ids[b * T_len + tt] >= 0 ? 1.f : 0.f;
+#pragma unroll
+        for (int q = 0; q < NCH; ++q) {
+            if constexpr (sizeof(T) == 2) {
+                wv[q][0] = __uint_as_float(wraw[q].x << 16); wv[q][1] = __uint_as_float(wraw[q].x & 0xFFFF0000u);
+                wv[q][2] = __uint_as_float(wraw[q].y << 16); wv[q][3] = __uint_as_float(wraw[q].y & 0xFFFF0000u);
+                yh[q][0] = __uint_as_float(hraw[q].x << 16); yh[q][1] = __uint_as_float(hraw[q].x & 0xFFFF0000u);
+                yh[q][2] = __uint_as_float(hraw[q].y << 16); yh[q][3] = __uint_as_float(hraw[q].y & 0xFFFF0000u);
+            } else {
+                wv[q][0] = __uint_as_float(wraw[q].x); wv[q][1] = __uint_as_float(wraw[q].y);
+                wv[q][2] = __uint_as_float(wraw[q].z); wv[q][3] = __uint_as_float(wraw[q].w);
+                yh[q][0] = __uint_as_float(hraw[q].x); yh[q][1] = __uint_as_float(hraw[q].y);
+                yh[q][2] = __uint_as_float(hraw[q].z); yh[q][3] = __uint_as_float(hraw[q].w);
+            }
+            if (y2) {
+                const int c0 = 4 * (lane + 64 * q);
+                const int sh = c0 - (c0 + 3 < V ? c0 : V - 4);   // 0, or 2 for the chunk that straddles the end (V even)
+                const float t4[4] = {ya[q].x, ya[q].y, yb[q].x, yb[q].y};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) yv[q][e] = (e + sh < 4) ? (sh == 0 ? t4[e] : t4[(e + 2) & 3]) : 0.f;
+            } else if (y != nullptr) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) yv[q][e] = ye[q][e];
             }
         }
 #pragma unroll
