@@ -181,21 +181,38 @@ extern "C" int c1v_pack_weights(const c1v_pack_desc* descs, int32_t n_desc, int3
 // latent head: sampling (:1188-1191), KL (:1202), decoder-input dropout (:1254) and their backward
 // ------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void latent_fwd_kernel(c1v_latent_args a) {
-    // one wave per sample
+    // one wave per sample; the columns go in rounds of 4 x 64 with every load of a round requested before the first value
+    // is used (clamped index, result masked): a plain `for (d = lane; d < D; d += 64)` loop paid one memory round trip per
+    // 64 columns, which was most of this small kernel's time
     const int lane = threadIdx.x & 63;
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (b >= a.B) return;
     const float* m = a.mlv + (int64_t)b * 2 * a.D;
     const float* lv = m + a.D;
+    const float* ep = a.eps + (int64_t)b * a.D;
+    const uint8_t* kd = a.keep_d ? a.keep_d + (int64_t)b * a.D : nullptr;
     float kl = 0.f;
-    for (int d = lane; d < a.D; d += 64) {
-        const float mv = m[d], l = lv[d];
-        const float z = mv + expf(a.std_scale * l) * a.eps[(int64_t)b * a.D + d];
-        kl += 1.0f + l - mv * mv - expf(l);
-        if (a.z_out) a.z_out[(int64_t)b * a.D + d] = z;
-        float zd = z;
-        if (a.keep_d) zd = a.keep_d[(int64_t)b * a.D + d] ? z / a.keep_prob : 0.0f;
-        store_any(a.zd_out, a.dtype, (int64_t)b * a.ldz + d, zd);
+    for (int d0 = 0; d0 < a.D; d0 += 256) {
+        float mv[4], l[4], e[4];
+        uint8_t k[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int d = d0 + lane + 64 * r, dc = d < a.D ? d : a.D - 1;
+            mv[r] = m[dc]; l[r] = lv[dc]; e[r] = ep[dc];
+            k[r] = kd ? kd[dc] : (uint8_t)1;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int d = d0 + lane + 64 * r;
+            if (d < a.D) {
+                const float z = mv[r] + expf(a.std_scale * l[r]) * e[r];
+                kl += 1.0f + l[r] - mv[r] * mv[r] - expf(l[r]);
+                if (a.z_out) a.z_out[(int64_t)b * a.D + d] = z;
+                float zd = z;
+                if (kd) zd = k[r] ? z / a.keep_prob : 0.0f;
+                store_any(a.zd_out, a.dtype, (int64_t)b * a.ldz + d, zd);
+            }
+        }
     }
     kl = wave_sum(kl);
     if (lane == 0 && a.kl_out) a.kl_out[b] = kl / (float)a.D;

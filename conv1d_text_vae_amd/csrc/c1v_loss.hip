@@ -30,6 +30,27 @@ __global__ __launch_bounds__(256) void l2norm_rows_kernel(const float* __restric
     const int orow = pos ? pos[row] : row;
     if (orow < 0) return;
     const float* yr = y + (int64_t)row * ldy;
+    // rows of at most 512 columns: every lane requests its columns (lane + 64 r, clamped) before the first is used, keeps
+    // them in registers and never reads the row a second time (the plain two-pass loop paid one round trip per 64 columns)
+    constexpr int R = 8;
+    if (kp <= 64 * R) {
+        float v[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) { const int c = lane + 64 * r; v[r] = yr[c < V ? c : V - 1]; }
+        float ss = 0.f;
+#pragma unroll
+        for (int r = 0; r < R; ++r) if (lane + 64 * r < V) ss += v[r] * v[r];
+        ss = wave_sum(ss);
+        const float rr = 1.0f / sqrtf(fmaxf(ss, 1e-12f));
+        if (lane == 0 && rnorm) rnorm[row] = rr;
+        const float sc = rr * qscale;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int c = lane + 64 * r;
+            if (c < kp) ElemTraits<T>::store(yhat, (int64_t)orow * kp + c, c < V ? v[r] * sc : 0.0f);
+        }
+        return;
+    }
     float ss = 0.f;
     for (int c = lane; c < V; c += 64) { const float v = yr[c]; ss += v * v; }
     ss = wave_sum(ss);
