@@ -36,7 +36,8 @@ class ConvArgs(C.Structure):
 
 class DenseArgs(C.Structure):
     _fields_ = [('a', C.c_void_p), ('dtype', C.c_int32), ('rows', C.c_int32), ('lda', C.c_int64), ('K', C.c_int32),
-                ('w_op', C.c_void_p), ('ldw', C.c_int64), ('n_out', C.c_int32), ('epi', Epilogue)]
+                ('w_op', C.c_void_p), ('ldw', C.c_int64), ('n_out', C.c_int32), ('epi', Epilogue), ('k_splits', C.c_int32),
+                ('split_stride', C.c_int64)]
 
 
 class WgradArgs(C.Structure):
@@ -77,7 +78,8 @@ class LatentArgs(C.Structure):
     _fields_ = [('mlv', C.c_void_p), ('B', C.c_int32), ('D', C.c_int32), ('eps', C.c_void_p), ('keep_d', C.c_void_p),
                 ('keep_prob', C.c_float), ('std_scale', C.c_float), ('zd_out', C.c_void_p), ('dtype', C.c_int32),
                 ('ldz', C.c_int64), ('z_out', C.c_void_p), ('kl_out', C.c_void_p), ('dzd', C.c_void_p),
-                ('B_global', C.c_int32), ('dmlv', C.c_void_p), ('ldd', C.c_int64)]
+                ('B_global', C.c_int32), ('dmlv', C.c_void_p), ('ldd', C.c_int64), ('n_parts', C.c_int32),
+                ('part_stride', C.c_int64)]
 
 
 class L2NormArgs(C.Structure):

@@ -86,6 +86,11 @@ static int dense_params(const c1v_dense_args* a, const char* what, NtParams& p) 
     p.A = (const char*)a->a; p.a_bstride_b = a->lda * es; p.lda_b = a->lda * es; p.a_off = 0;
     p.W = (const char*)a->w_op; p.ldw_b = a->ldw * es; p.Kb = (int64_t)a->K * es;
     C1V_REQUIRE(a->epi.row_mode == C1V_ROW_STORE || a->epi.row_mode == C1V_ROW_UNPOOL, "%s: dense epilogue supports STORE / UNPOOL only", what);
+    if (a->k_splits > 1) {
+        const int64_t kt = c1v_cdiv(p.Kb, 128);
+        C1V_REQUIRE(a->k_splits <= kt && a->split_stride > 0, "%s: bad split-K (k_splits=%d, K tiles=%lld)", what, a->k_splits, (long long)kt);
+        p.ksplits = a->k_splits; p.kt_per_split = (int)c1v_cdiv(kt, a->k_splits); p.dst_split_stride = a->split_stride;
+    }
     return c1v_fill_epi(a->epi, p.e, a->rows, 1, 1, a->n_out);
 }
 static int dense_common(const c1v_dense_args* a, void* stream, const char* what) {

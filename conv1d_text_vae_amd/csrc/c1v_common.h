@@ -104,6 +104,7 @@ struct NtParams {
     const char* A; int64_t a_bstride_b; int64_t lda_b; int a_off;   // A row(m): b=m/Le,u=m%Le -> A + b*a_bstride_b + (a_off+u)*lda_b
     const char* W; int64_t ldw_b;
     int64_t Kb;                                                      // K in bytes
+    int ksplits, kt_per_split; int64_t dst_split_stride;             // split-K (grid z): K tiles [s*kt_per_split, ..) -> dst + s*stride
     EpiDev e;
 };
 

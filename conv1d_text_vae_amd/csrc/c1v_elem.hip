@@ -201,6 +201,24 @@ __global__ __launch_bounds__(256) void latent_fwd_kernel(c1v_latent_args a) {
             mv[r] = m[dc]; l[r] = lv[dc]; e[r] = ep[dc];
             k[r] = kd ? kd[dc] : (uint8_t)1;
         }
+        if (a.n_parts > 1) {
+            // split-K heads GEMM: mlv arrives as partial slabs; sum them in slab order and write the sum back to slab 0
+            for (int s2 = 1; s2 < a.n_parts; ++s2) {
+                float pm[4], pl[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int d = d0 + lane + 64 * r, dc = d < a.D ? d : a.D - 1;
+                    pm[r] = m[(int64_t)s2 * a.part_stride + dc]; pl[r] = lv[(int64_t)s2 * a.part_stride + dc];
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { mv[r] += pm[r]; l[r] += pl[r]; }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int d = d0 + lane + 64 * r;
+                if (d < a.D) { ((float*)m)[d] = mv[r]; ((float*)lv)[d] = l[r]; }
+            }
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int d = d0 + lane + 64 * r;

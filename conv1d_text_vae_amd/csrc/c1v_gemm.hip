@@ -6,7 +6,7 @@ template <typename T, int BM, int BN, int NS>
 __global__ __launch_bounds__(C1V_GEMM_THREADS) void gemm_nt_kernel(const NtParams p) {
     static_assert(sizeof(NtParams) + 192 > 0x100, "kernarg lines touched below");
     c1v_touch_kernarg<4>();
-    nt_body<T, BM, BN, NS>(p, blockIdx.x, blockIdx.y, blockIdx.x + gridDim.x * blockIdx.y);
+    nt_body<T, BM, BN, NS>(p, blockIdx.x, blockIdx.y, blockIdx.x + gridDim.x * blockIdx.y, blockIdx.z);
 }
 template <typename T>
 __global__ __launch_bounds__(C1V_GEMM_THREADS) void gemm_tn_kernel(const TnParams p) {
@@ -19,7 +19,7 @@ __global__ __launch_bounds__(C1V_GEMM_THREADS) void gemm_tn_kernel(const TnParam
 template <typename T, int BM, int BN, int NS> static void launch_nt_v(const NtParams& p, hipStream_t st) {
     constexpr int LDS = NS * (BM + BN) * 128;
     static bool once = (set_lds(gemm_nt_kernel<T, BM, BN, NS>, LDS), true); (void)once;
-    dim3 grid((unsigned)c1v_cdiv(p.e.M, BM), (unsigned)c1v_cdiv(p.e.N, BN));
+    dim3 grid((unsigned)c1v_cdiv(p.e.M, BM), (unsigned)c1v_cdiv(p.e.N, BN), (unsigned)(p.ksplits > 1 ? p.ksplits : 1));
     hipLaunchKernelGGL((gemm_nt_kernel<T, BM, BN, NS>), grid, dim3(C1V_GEMM_THREADS), LDS, st, p);
 }
 
@@ -40,6 +40,11 @@ int c1v_check_nt(const NtParams& p) {
                 (long long)p.ldw_b, (long long)p.Kb);
     const bool pairs = p.e.row_mode == C1V_ROW_POOL2 || p.e.row_mode == C1V_ROW_PAIRSUM;
     C1V_REQUIRE(!pairs || (p.e.Le % 2 == 0), "pair epilogue needs an even row enumeration (Le=%d)", p.e.Le);
+    if (p.ksplits > 1) {
+        C1V_REQUIRE(p.e.row_mode == C1V_ROW_STORE && !p.e.relu && !p.e.exp2 && p.e.act == nullptr && p.e.keep == nullptr,
+                    "split-K needs a plain STORE epilogue (partial sums are not final values)");
+        C1V_REQUIRE(p.kt_per_split > 0 && (int64_t)p.kt_per_split * p.ksplits >= c1v_cdiv(p.Kb, 128), "split-K ranges do not cover K");
+    }
     return 0;
 }
 

@@ -446,7 +446,7 @@ extern "C" int c1v_debug_read_nt(unsigned long long* dst, int n) {
 constexpr int C1V_GEMM_THREADS = 384;
 
 template <typename T, int BM, int BN, int NS>
-__device__ __forceinline__ void nt_body(const NtParams& p, const int bx, const int by, const int wg_linear) {
+__device__ __forceinline__ void nt_body(const NtParams& p, const int bx, const int by, const int wg_linear, const int ks = 0) {
 #ifdef NT_STAMP
     unsigned long long stamp[16];
 #endif
@@ -463,7 +463,12 @@ __device__ __forceinline__ void nt_body(const NtParams& p, const int bx, const i
     const int wm = (wave >> 1) & 1, wn = wave & 1;
     const int m0 = bx * BM, n0 = by * BN;
     const RowDiv rd = make_rowdiv(m0, p.e.Le);
-    const int KT = (int)((p.Kb + 127) / 128);
+    // split-K: this workgroup owns K tiles [kt0, kt0 + KT) and the destination slab `ks`
+    const int KT_all = (int)((p.Kb + 127) / 128);
+    const int kt0 = p.ksplits > 1 ? ks * p.kt_per_split : 0;
+    const int KT = p.ksplits > 1 ? (KT_all - kt0 < p.kt_per_split ? (KT_all - kt0 > 0 ? KT_all - kt0 : 0) : p.kt_per_split) : KT_all;
+    EpiDev ev = p.e;                                   // (fields are wave-uniform scalars)
+    if (p.ksplits > 1) ev.dst = (char*)ev.dst + (int64_t)ks * p.dst_split_stride * (ev.dst_dtype == C1V_F32 ? 4 : 2);
 
     if (wave >= 4) {
         // ---- feeder: lane (prow, ppos) of request i fills position ppos of tile row 8 i + prow, which must hold logical
@@ -475,7 +480,7 @@ __device__ __forceinline__ void nt_body(const NtParams& p, const int bx, const i
             for (int i = 0; i < IPT; ++i) {
                 const int row = 8 * i + prow;
                 int b, u;
-                rowdiv(rd, m0 + row < p.e.M ? row : p.e.M - 1 - m0, b, u);
+                rowdiv(rd, m0 + row < ev.M ? row : ev.M - 1 - m0, b, u);
                 src[i] = p.A + (int64_t)b * p.a_bstride_b + (int64_t)(p.a_off + u) * p.lda_b + ((ppos ^ ((row >> 1) & 7)) << 4);
             }
         } else {
@@ -483,14 +488,14 @@ __device__ __forceinline__ void nt_body(const NtParams& p, const int bx, const i
             for (int i = 0; i < IPT; ++i) {
                 const int row = 8 * i + prow;
                 int n = n0 + row;
-                if (n >= p.e.N) n = p.e.N - 1;
+                if (n >= ev.N) n = ev.N - 1;
                 src[i] = p.W + (int64_t)n * p.ldw_b + ((ppos ^ ((row >> 1) & 7)) << 4);
             }
         }
         const int dst0 = wave == 4 ? 0 : BM * 128;
         auto issue = [&](int kt) {
             char* d = smem + (kt % NS) * STAGE + dst0;
-            const int64_t ko = (int64_t)kt * 128;
+            const int64_t ko = (int64_t)(kt0 + kt) * 128;
 #pragma unroll
             for (int i = 0; i < IPT; ++i) glds16(src[i] + ko, d + i * 1024);
         };
@@ -516,33 +521,35 @@ __device__ __forceinline__ void nt_body(const NtParams& p, const int bx, const i
 
     // bias of this thread's epilogue channel group (see epilogue_rows): requested now, consumed after the K loop
     float bias4[4] = {0.f, 0.f, 0.f, 0.f};
-    const int fastw = p.e.fastw;                       // wave-uniform: 4 / 2 = vectorised epilogue, 0 = element-wise
+    const int fastw = ev.fastw;                       // wave-uniform: 4 / 2 = vectorised epilogue, 0 = element-wise
     EpiState es;
     {
         const int nbias = n0 + 4 * (tid % (BN / 4));
-        if (p.e.bias && p.e.bias_row_w > 0) {           // rows padded to reshape_w channels: bias index = t * bias_row_w + c
-            const int tb = nbias / p.e.reshape_w, cb = nbias - tb * p.e.reshape_w;
+        if (ks > 0) {
+            // split-K: the bias belongs to slab 0
+        } else if (ev.bias && ev.bias_row_w > 0) {           // rows padded to reshape_w channels: bias index = t * bias_row_w + c
+            const int tb = nbias / ev.reshape_w, cb = nbias - tb * ev.reshape_w;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 int t2 = tb, c2 = cb + k;
-                if (c2 >= p.e.reshape_w) { c2 -= p.e.reshape_w; ++t2; }
-                bias4[k] = (nbias + k < p.e.N && c2 < p.e.bias_row_w) ? p.e.bias[t2 * p.e.bias_row_w + c2] : 0.0f;
+                if (c2 >= ev.reshape_w) { c2 -= ev.reshape_w; ++t2; }
+                bias4[k] = (nbias + k < ev.N && c2 < ev.bias_row_w) ? ev.bias[t2 * ev.bias_row_w + c2] : 0.0f;
             }
-        } else if (p.e.bias) {
+        } else if (ev.bias) {
             if (fastw == 4) {
-                if (nbias < p.e.N) { const float4 b = *(const float4*)(p.e.bias + nbias); bias4[0] = b.x; bias4[1] = b.y; bias4[2] = b.z; bias4[3] = b.w; }
+                if (nbias < ev.N) { const float4 b = *(const float4*)(ev.bias + nbias); bias4[0] = b.x; bias4[1] = b.y; bias4[2] = b.z; bias4[3] = b.w; }
             } else if (fastw == 2) {
-                if (nbias < p.e.N) { const float2 b = *(const float2*)(p.e.bias + nbias); bias4[0] = b.x; bias4[1] = b.y; }
-                if (nbias + 2 < p.e.N) { const float2 b = *(const float2*)(p.e.bias + nbias + 2); bias4[2] = b.x; bias4[3] = b.y; }
+                if (nbias < ev.N) { const float2 b = *(const float2*)(ev.bias + nbias); bias4[0] = b.x; bias4[1] = b.y; }
+                if (nbias + 2 < ev.N) { const float2 b = *(const float2*)(ev.bias + nbias + 2); bias4[2] = b.x; bias4[3] = b.y; }
             } else {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) bias4[k] = nbias + k < p.e.N ? p.e.bias[nbias + k] : 0.0f;
+                for (int k = 0; k < 4; ++k) bias4[k] = nbias + k < ev.N ? ev.bias[nbias + k] : 0.0f;
             }
         }
     }
     // epilogue inputs of the first chunk of rows: requested while the feeders fill the ring
-    if (fastw == 4) { C1V_EPI_DISPATCH(4, (epi_load<BM, BN, MODE_, VW_>(p.e, rd, es, m0, n0, tid, 0))) }
-    else if (fastw == 2) { C1V_EPI_DISPATCH(2, (epi_load<BM, BN, MODE_, VW_>(p.e, rd, es, m0, n0, tid, 0))) }
+    if (fastw == 4) { C1V_EPI_DISPATCH(4, (epi_load<BM, BN, MODE_, VW_>(ev, rd, es, m0, n0, tid, 0))) }
+    else if (fastw == 2) { C1V_EPI_DISPATCH(2, (epi_load<BM, BN, MODE_, VW_>(ev, rd, es, m0, n0, tid, 0))) }
     NT_T(1);
 
     for (int kt = 0; kt < KT; ++kt) {
@@ -584,15 +591,15 @@ __device__ __forceinline__ void nt_body(const NtParams& p, const int bx, const i
                 ct[(wm * WTM + i * 16 + (lane >> 4) * 4 + r) * LDC + wn * WTN + j * 16 + (lane & 15)] = acc[i][j][r];
     __syncthreads();
     NT_T(5);
-    if (fastw == 4) { C1V_EPI_DISPATCH(4, (epi_fast_rows<BM, BN, MODE_, VW_>(p.e, rd, es, ct, LDC, m0, n0, tid, bias4))) }
-    else if (fastw == 2) { C1V_EPI_DISPATCH(2, (epi_fast_rows<BM, BN, MODE_, VW_>(p.e, rd, es, ct, LDC, m0, n0, tid, bias4))) }
+    if (fastw == 4) { C1V_EPI_DISPATCH(4, (epi_fast_rows<BM, BN, MODE_, VW_>(ev, rd, es, ct, LDC, m0, n0, tid, bias4))) }
+    else if (fastw == 2) { C1V_EPI_DISPATCH(2, (epi_fast_rows<BM, BN, MODE_, VW_>(ev, rd, es, ct, LDC, m0, n0, tid, bias4))) }
     else {
-        switch (p.e.row_mode) {                        // wave-uniform; one specialised epilogue each
-            case C1V_ROW_STORE:   epilogue_rows<BM, BN, C1V_ROW_STORE>(p.e, ct, LDC, m0, n0, tid, bias4); break;
-            case C1V_ROW_POOL2:   epilogue_rows<BM, BN, C1V_ROW_POOL2>(p.e, ct, LDC, m0, n0, tid, bias4); break;
-            case C1V_ROW_UP2:     epilogue_rows<BM, BN, C1V_ROW_UP2>(p.e, ct, LDC, m0, n0, tid, bias4); break;
-            case C1V_ROW_PAIRSUM: epilogue_rows<BM, BN, C1V_ROW_PAIRSUM>(p.e, ct, LDC, m0, n0, tid, bias4); break;
-            default:              epilogue_rows<BM, BN, C1V_ROW_UNPOOL>(p.e, ct, LDC, m0, n0, tid, bias4); break;
+        switch (ev.row_mode) {                        // wave-uniform; one specialised epilogue each
+            case C1V_ROW_STORE:   epilogue_rows<BM, BN, C1V_ROW_STORE>(ev, ct, LDC, m0, n0, tid, bias4); break;
+            case C1V_ROW_POOL2:   epilogue_rows<BM, BN, C1V_ROW_POOL2>(ev, ct, LDC, m0, n0, tid, bias4); break;
+            case C1V_ROW_UP2:     epilogue_rows<BM, BN, C1V_ROW_UP2>(ev, ct, LDC, m0, n0, tid, bias4); break;
+            case C1V_ROW_PAIRSUM: epilogue_rows<BM, BN, C1V_ROW_PAIRSUM>(ev, ct, LDC, m0, n0, tid, bias4); break;
+            default:              epilogue_rows<BM, BN, C1V_ROW_UNPOOL>(ev, ct, LDC, m0, n0, tid, bias4); break;
         }
     }
 #ifdef NT_STAMP

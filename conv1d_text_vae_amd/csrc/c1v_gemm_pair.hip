@@ -47,6 +47,7 @@ template <typename T> static int launch_pair_t(PairParams& pp, hipStream_t st) {
 
 int c1v_launch_pair(int dtype, const NtParams& nt, const TnParams& tn, hipStream_t st) {
     if (c1v_check_nt(nt) || c1v_check_tn(tn)) return -1;
+    C1V_REQUIRE(nt.ksplits <= 1, "pair launch: split-K dgrad is not supported");
     PairParams pp;
     pp.nt = nt; pp.tn = tn;
     pp.tn_gi = (int)c1v_cdiv(tn.I, 128);

@@ -142,7 +142,14 @@ class VAEEngine:
         self.D = D
         self.Dp = _pad(D, 64)
         self.D2p = _pad(2 * D, 64)
-        self.mlv = z(B, 2 * D)
+        # The heads GEMM (M = batch, K = flat) has few output tiles and a long K: it runs split-K over this many workgroups per
+        # tile and the latent kernel sums the partial slabs (slab 0 = self.mlv holds the complete values afterwards)
+        heads_tiles = ((B + 63) // 64) * ((2 * D + 63) // 64)
+        heads_kt = (self.flat_p * (2 if self.tdt != torch.float32 else 4) + 127) // 128
+        self.heads_splits = int(max(1, min(8, 256 // max(1, heads_tiles), heads_kt // 3))) \
+            if os.environ.get('C1V_SPLITK', '1') == '1' else 1
+        self.mlv_parts = z(self.heads_splits, B, 2 * D)
+        self.mlv = self.mlv_parts[0]
         self.eps = z(B, D)
         self.eps_zero = z(B, D)
         self.keep_e = torch.ones(B, self.flat, dtype=torch.uint8, device=self.dev)
@@ -394,14 +401,16 @@ class VAEEngine:
             mlv_seq = L.Seq(self.mlv.data_ptr(), L.F32, B, 2 * self.D, 0, 1, 2 * self.D, 2 * self.D)
             e = self._epi(mlv_seq, L.ROW_STORE, self._bias_ptr('z_heads/bias'))
             ops.append(op('c1v_dense_fwd', L.DenseArgs(self.H.t.data_ptr(), self.code, B, self.flat_p, self.flat_p,
-                                                       self.wop['heads_fwd'].data_ptr(), self.wld['heads_fwd'], 2 * self.D, e)))
+                                                       self.wop['heads_fwd'].data_ptr(), self.wld['heads_fwd'], 2 * self.D, e,
+                                                       self.heads_splits, B * 2 * self.D)))
             return ops
 
         def latent(train: bool, sample: bool):
             a = L.LatentArgs(self.mlv.data_ptr(), B, self.D, (self.eps if sample else self.eps_zero).data_ptr(),
                              self.keep_d.data_ptr() if train else None, KEEP_PROB, self.std_scale if sample else 0.0,
                              self.zd.data_ptr(), self.code, self.Dp, self.z_out.data_ptr(), self.kl_b.data_ptr(),
-                             self.dzd.data_ptr(), self.Bg, self.dmlv.data_ptr(), self.D2p)
+                             self.dzd.data_ptr(), self.Bg, self.dmlv.data_ptr(), self.D2p,
+                             self.heads_splits, B * 2 * self.D)
             return a
 
         self._lat_train = latent(True, True)
@@ -935,7 +944,7 @@ class VAEEngine:
     def encode(self, use_graph: bool = True) -> torch.Tensor:
         """vae_encoder_.predict_on_batch (:404): z_mean of the resident batch, [B, latent] fp32 (device)."""
         self._ensure_packed()
-        ops = self.ops_pack_in + self.ops_enc_infer
+        ops = self.ops_pack_in + self.ops_enc_infer + (self.ops_lat_infer if self.heads_splits > 1 else [])   # sums the slabs
         if use_graph:
             self._graph('encode', ops)
         else:
@@ -955,7 +964,7 @@ class VAEEngine:
 
     def decode_latent(self, z: torch.Tensor) -> torch.Tensor:
         """vae_decoder_.predict_on_batch(z): z [B, latent] fp32 -> y [B, T_out, V] fp32."""
-        self.mlv.zero_()
+        self.mlv_parts.zero_()
         self.mlv[:, :self.D].copy_(z)
         self._run(self.ops_lat_infer + self.ops_dec)
         return self.Y.t[: self.B * self.g.output_text_size * self.V].view(self.B, self.g.output_text_size, self.V)

@@ -112,6 +112,11 @@ typedef struct c1v_dense_args {
     int64_t      ldw;
     int32_t      n_out;
     c1v_epilogue epi;
+    int32_t      k_splits;    /* 0 / 1 = off.  > 1: K is cut into k_splits ranges of whole 128-byte tiles, one workgroup each
+                                 (a GEMM with few output tiles and a long K then covers the chip); split s adds its partial
+                                 sums into epi.dst + s*split_stride elements (bias in split 0 only), the consumer sums the
+                                 slabs (c1v_latent_head_fwd: mlv_parts).  STORE epilogue without relu / act / keep only. */
+    int64_t      split_stride;
 } c1v_dense_args;
 int c1v_dense_fwd(const c1v_dense_args*, void* stream);
 int c1v_dense_dgrad(const c1v_dense_args*, void* stream);
@@ -199,6 +204,10 @@ typedef struct c1v_latent_args {
     const float* dzd;            /* [B][D] f32 */
     int32_t B_global;
     void* dmlv; int64_t ldd;
+    /* forward only, optional: mlv arrives as n_parts partial slabs (c1v_dense_fwd with k_splits) part_stride elements apart,
+       starting at mlv; they are summed in slab order and the sum is written back to slab 0 (= mlv, then the complete
+       [z_mean | z_log_var] the backward and transform() read) */
+    int32_t n_parts; int64_t part_stride;
 } c1v_latent_args;
 int c1v_latent_head_fwd(const c1v_latent_args*, void* stream);
 int c1v_latent_head_bwd(const c1v_latent_args*, void* stream);

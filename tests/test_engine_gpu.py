@@ -38,6 +38,7 @@ CASES = {
     'k2': dict(B=5, T_in=9, T_out=9, E=40, n_filters=(33,), k=2, D=3, N=130),
     'mid': dict(B=16, T_in=20, T_out=18, E=62, n_filters=(48, 40), k=3, D=24, N=300),
     'wide': dict(B=8, T_in=16, T_out=16, E=100, n_filters=(32,), k=3, D=16, N=500),   # kp=128: unfused loss path in bf16
+    'longflat': dict(B=8, T_in=70, T_out=20, E=30, n_filters=(64,), k=3, D=16, N=90),   # flat = 2176: split-K heads GEMM (8 slabs)
 }
 
 
@@ -80,6 +81,8 @@ def test_train_forward_backward_parity(name, dtype):
     loss, grads, acts = O.train_forward_backward(og, p64, Wv.astype(np.float64), x.astype(np.float64), ids,
                                                  eps.astype(np.float64), mask_e, mask_d)
     eng = build_engine(c, og, params, Wv, dtype)
+    if name == 'longflat':
+        assert eng.heads_splits == 8
     load_fixed(eng, x, ids, eps, mask_e, mask_d)
     eng._run(eng.train_ops(False))
     torch.cuda.synchronize()
