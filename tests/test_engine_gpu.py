@@ -228,8 +228,9 @@ def test_device_rng_step_changes_and_counter_advances():
 
 
 @pytest.mark.parametrize('dtype', ['f32', 'bf16'])
-def test_inference_encode_reconstruct_postprocess(dtype):
-    c = CASES['mid']
+@pytest.mark.parametrize('case', ['mid', 'longflat'])
+def test_inference_encode_reconstruct_postprocess(dtype, case):
+    c = CASES[case]
     og, params, Wv, x, ids, eps, mask_e, mask_d = make_case(c, seed=4)
     p64 = {k: v.astype(np.float64) for k, v in params.items()}
     zm, zl = O.encoder_forward(og, p64, x.astype(np.float64))
@@ -246,6 +247,9 @@ def test_inference_encode_reconstruct_postprocess(dtype):
     ref_post = O.postprocess_reconstructed_word_vectors(ygpu)
     np.testing.assert_allclose(post, ref_post, rtol=1e-5, atol=1e-6)
     assert np.array_equal(eng.end_idx.cpu().numpy(), O.eos_end_index(ygpu))
+    # vae_decoder_.predict_on_batch(z) alone (the split-K slabs of the heads GEMM must not leak into it)
+    y2 = eng.decode_latent(torch.from_numpy(zm.astype(np.float32)).to(eng.dev)).cpu().numpy()
+    assert rel_err(y2, y) < tol
 
 
 @pytest.mark.parametrize('dtype', ['f32', 'bf16'])
