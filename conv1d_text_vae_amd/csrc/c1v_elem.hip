@@ -49,7 +49,10 @@ __device__ __forceinline__ void pack_input_body(const float* __restrict__ src, i
         }
         float v[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = c0 + k < C ? src[row * C + c0 + k] : 0.0f;
+        for (int k = 0; k < 8; ++k) {              // unconditional load (clamped), masked afterwards: no branch, no wait per element
+            const float t2 = src[row * C + (c0 + k < C ? c0 + k : C - 1)];
+            v[k] = c0 + k < C ? t2 : 0.0f;
+        }
         store8<T>(dst, b * dst.bstride + (int64_t)(dst.off + t) * dst.cp + c0, v);
     }
 }
@@ -75,7 +78,10 @@ __device__ __forceinline__ void gather_input_body(const float* __restrict__ tabl
         const int id = ids[row];
         float v[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = (c0 + k < C && id >= 0) ? table[(int64_t)id * ld + c0 + k] : 0.0f;
+        for (int k = 0; k < 8; ++k) {
+            const float t2 = table[(int64_t)(id >= 0 ? id : 0) * ld + (c0 + k < C ? c0 + k : C - 1)];
+            v[k] = (c0 + k < C && id >= 0) ? t2 : 0.0f;
+        }
         store8<T>(dst, b * dst.bstride + (int64_t)(dst.off + t) * dst.cp + c0, v);
     }
 }
@@ -147,14 +153,16 @@ __device__ __forceinline__ void pack_weights_body(const c1v_pack_desc* __restric
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int c = c0 + ty + 8 * k, n = n0 + tx;
-            tile[ty + 8 * k][tx] = (c < d.c_count && n < d.n_count) ? src[(int64_t)c * d.s_c + (int64_t)n * d.s_n] : 0.0f;
+            const float t2 = src[(int64_t)(c < d.c_count ? c : d.c_count - 1) * d.s_c + (int64_t)(n < d.n_count ? n : d.n_count - 1) * d.s_n];
+            tile[ty + 8 * k][tx] = (c < d.c_count && n < d.n_count) ? t2 : 0.0f;
         }
     } else {
         // c is the fast axis of the source: read rows of c
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int n = n0 + ty + 8 * k, c = c0 + tx;
-            tile[tx][ty + 8 * k] = (c < d.c_count && n < d.n_count) ? src[(int64_t)c * d.s_c + (int64_t)n * d.s_n] : 0.0f;
+            const float t2 = src[(int64_t)(c < d.c_count ? c : d.c_count - 1) * d.s_c + (int64_t)(n < d.n_count ? n : d.n_count - 1) * d.s_n];
+            tile[tx][ty + 8 * k] = (c < d.c_count && n < d.n_count) ? t2 : 0.0f;
         }
     }
     __syncthreads();
@@ -335,12 +343,25 @@ __global__ __launch_bounds__(256) void grad_finalize_kernel(const c1v_seg_desc* 
         if (vec) {
             float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
             if (!d.frozen) {
+                // slabs in (split, rep) order, four independent requests per round, no integer division in the loop
                 const int ns = d.splits * d.reps;
-#pragma unroll 4
-                for (int s = 0; s < ns; ++s) {
-                    const int sp = s / d.reps, r = s - sp * d.reps;
-                    const float4 v = *(const float4*)(d.slab + (int64_t)sp * d.slab_stride + (int64_t)r * d.rep_stride + i);
-                    g.x += v.x; g.y += v.y; g.z += v.z; g.w += v.w;
+                int64_t off = 0;
+                int sp = 0, r = 0;
+                for (int s0 = 0; s0 < ns; s0 += 4) {
+                    int64_t o[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        o[q] = off;
+                        if (s0 + q + 1 < ns) {
+                            ++r; off += d.rep_stride;
+                            if (r == d.reps) { r = 0; ++sp; off = (int64_t)sp * d.slab_stride; }
+                        }
+                    }
+                    float4 v[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = *(const float4*)(d.slab + o[q] + i);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) if (s0 + q < ns) { g.x += v[q].x; g.y += v[q].y; g.z += v[q].z; g.w += v[q].w; }
                 }
             }
             *(float4*)(grad + d.offset + i) = g;
