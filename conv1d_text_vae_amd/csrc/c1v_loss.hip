@@ -196,6 +196,20 @@ void vocab_stream_kernel(const bf16_raw* __restrict__ yhat, int M, const bf16_ra
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev) :: "memory");
     const unsigned long long tstart = tprev;
 #endif
+    // ACCUM mode runs a tile as  GEMM1(t) | wait + barrier | GEMM2(t)  with ONE barrier, in the middle of the tile:
+    //   * it publishes tile t+1 (requested during GEMM2 of tile t-1) and proves that every wave is done with tile t-1, whose
+    //     stage the request for tile t+2 -- sent right after it, behind the GEMM2 batches -- overwrites;
+    //   * nothing separates the end of GEMM2(t) from GEMM1(t+1), so the first fragments of tile t+1 are fetched behind the
+    //     last GEMM2 batch of tile t (with the barrier at the end of the tile every tile began with an exposed LDS round
+    //     trip and a barrier skew: GEMM1's first half took 1450 cycles against 900 for the second, exp2 work included).
+    // The other modes (no GEMM2) keep the barrier at the end of the tile.
+    uint4 a1[2][G1];
+    if constexpr (MODE == VS_ACCUM) {
+        if (t_begin < t_end) {
+#pragma unroll
+            for (int j = 0; j < G1; ++j) a1[0][j] = *(const uint4*)(smem + vs_off<CB>(l31, 2 * j + h));
+        }
+    }
     for (int t = t_begin; t < t_end; ++t) {
         VS_T(7);
         const int stage = (t - t_begin) % VS_STAGES;
@@ -252,10 +266,11 @@ void vocab_stream_kernel(const bf16_raw* __restrict__ yhat, int M, const bf16_ra
             }
         };
 
-        uint4 a1[2][G1];
         uint4 a2[3][CG * 2];
+        if constexpr (MODE != VS_ACCUM) {
 #pragma unroll
-        for (int j = 0; j < G1; ++j) a1[0][j] = ld1(0, j);
+            for (int j = 0; j < G1; ++j) a1[0][j] = ld1(0, j);
+        }
 #pragma unroll
         for (int q = 0; q < Q1; ++q) {
             const int nb = q / NB1, s0 = (q % NB1) * G1;
@@ -282,9 +297,17 @@ void vocab_stream_kernel(const bf16_raw* __restrict__ yhat, int M, const bf16_ra
 #if !(defined(VS_ABLATE) && (VS_ABLATE & 8))
             // the request for tile t+2 goes out in the shadow of the nb=0 MFMAs (its stage was released by the barrier
             // that ended tile t-1), a few pieces per batch
-            if (nb == 0 && more) {
+            // Each wave sends ALL its pieces behind ONE batch, a different batch per wave: a request occupies the CU's
+            // address path for ~16 cycles and blocks the issuing wave meanwhile; when the four waves issued a few pieces
+            // each behind the same batches they queued behind one another (measured: ~700 cycles per tile and wave).
+            if (MODE != VS_ACCUM && (Q1 >= 8 ? q == 2 * wave : (nb == 0)) && more) {
+                if constexpr (Q1 >= 8) {
 #pragma unroll
-                for (int i = q * Cfg::PPW / NB1; i < (q + 1) * Cfg::PPW / NB1; ++i) stage_piece(t + 2, (stage + 2) % VS_STAGES, i);
+                    for (int i = 0; i < Cfg::PPW; ++i) stage_piece(t + 2, (stage + 2) % VS_STAGES, i);
+                } else {
+#pragma unroll
+                    for (int i = q * Cfg::PPW / NB1; i < (q + 1) * Cfg::PPW / NB1; ++i) stage_piece(t + 2, (stage + 2) % VS_STAGES, i);
+                }
             }
 #endif
             if (nb == 1) post(0, (q - NB1) * 16 / NB1, (q - NB1 + 1) * 16 / NB1);
@@ -301,6 +324,14 @@ void vocab_stream_kernel(const bf16_raw* __restrict__ yhat, int M, const bf16_ra
             for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
                 for (int j = 0; j < 8; ++j) pf[0][ks][j] = (__bf16)S[0][8 * ks + j];
+#if !(defined(VS_ABLATE) && (VS_ABLATE & 8))
+            // the tile's only barrier: tile t+1 (this wave's pieces: everything it has in flight) is in LDS, tile t-1 is dead
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            VS_T(4);
+            __syncthreads();
+            VS_T(5);
+            const char* swn = smem + ((t + 1 - t_begin) % VS_STAGES) * Cfg::STAGE;
+#endif
 #pragma unroll
             for (int q = 0; q < Q2; ++q) {
                 const int nb = q / NB2, cb0 = (q % NB2) * CG;
@@ -327,6 +358,18 @@ void vocab_stream_kernel(const bf16_raw* __restrict__ yhat, int M, const bf16_ra
 #endif
                         U[cb0 + c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a2[q % 3][c * 2 + ks]), pf[nb][ks],
                                                                              U[cb0 + c], 0, 0, 0);
+#if !(defined(VS_ABLATE) && (VS_ABLATE & 8))
+                // request for tile t+2: every wave sends all its pieces behind one batch, a different batch per wave
+                if ((Q2 >= 8 ? q == 2 * wave : q == 0) && more) {
+#pragma unroll
+                    for (int i = 0; i < Cfg::PPW; ++i) stage_piece(t + 2, (stage + 2) % VS_STAGES, i);
+                }
+                // first GEMM1 fragments of tile t+1, behind the last batch
+                if (q == Q2 - 1 && t + 1 < t_end) {
+#pragma unroll
+                    for (int j = 0; j < G1; ++j) a1[0][j] = *(const uint4*)(swn + vs_off<CB>(l31, 2 * j + h));
+                }
+#endif
                 if (nb == 0) post(1, q * 16 / NB2, (q + 1) * 16 / NB2);
                 __builtin_amdgcn_sched_barrier(0);
                 if (q == NB2 - 1) VS_T(2);
@@ -334,12 +377,14 @@ void vocab_stream_kernel(const bf16_raw* __restrict__ yhat, int M, const bf16_ra
             }
         }
 #if !(defined(VS_ABLATE) && (VS_ABLATE & 8))
-        // tile t+1 must have landed; tile t+2's request (the youngest PPW loads of this wave) stays in flight
-        if (t + 2 < t_end) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Cfg::PPW) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        VS_T(4);
-        __syncthreads();
-        VS_T(5);
+        if constexpr (MODE != VS_ACCUM) {
+            // tile t+1 must have landed; tile t+2's request (the youngest PPW loads of this wave) stays in flight
+            if (t + 2 < t_end) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Cfg::PPW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            VS_T(4);
+            __syncthreads();
+            VS_T(5);
+        }
 #endif
     }
 #ifdef VS_STAMP
