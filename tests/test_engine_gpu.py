@@ -38,6 +38,7 @@ CASES = {
     'k2': dict(B=5, T_in=9, T_out=9, E=40, n_filters=(33,), k=2, D=3, N=130),
     'mid': dict(B=16, T_in=20, T_out=18, E=62, n_filters=(48, 40), k=3, D=24, N=300),
     'wide': dict(B=8, T_in=16, T_out=16, E=100, n_filters=(32,), k=3, D=16, N=500),   # kp=128: unfused loss path in bf16
+    'big128': dict(B=2048, T_in=32, T_out=32, E=62, n_filters=(128,), k=3, D=32, N=200),   # 128x128 GEMM tiles (>= 384 of them)
     'longflat': dict(B=8, T_in=70, T_out=20, E=30, n_filters=(64,), k=3, D=16, N=90),   # flat = 2176: split-K heads GEMM (8 slabs)
 }
 
