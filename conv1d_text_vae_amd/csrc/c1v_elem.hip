@@ -211,15 +211,23 @@ __global__ __launch_bounds__(256) void latent_fwd_kernel(c1v_latent_args a) {
         }
         if (a.n_parts > 1) {
             // split-K heads GEMM: mlv arrives as partial slabs; sum them in slab order and write the sum back to slab 0
-            for (int s2 = 1; s2 < a.n_parts; ++s2) {
-                float pm[4], pl[4];
+            for (int s2 = 1; s2 < a.n_parts; s2 += 4) {          // four slabs (32 requests) per round
+                float pm[4][4], pl[4][4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int d = d0 + lane + 64 * r, dc = d < a.D ? d : a.D - 1;
-                    pm[r] = m[(int64_t)s2 * a.part_stride + dc]; pl[r] = lv[(int64_t)s2 * a.part_stride + dc];
+                for (int i = 0; i < 4; ++i) {
+                    const int64_t so = (int64_t)(s2 + i < a.n_parts ? s2 + i : a.n_parts - 1) * a.part_stride;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int d = d0 + lane + 64 * r, dc = d < a.D ? d : a.D - 1;
+                        pm[i][r] = m[so + dc]; pl[i][r] = lv[so + dc];
+                    }
                 }
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { mv[r] += pm[r]; l[r] += pl[r]; }
+                for (int i = 0; i < 4; ++i)
+                    if (s2 + i < a.n_parts) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { mv[r] += pm[i][r]; l[r] += pl[i][r]; }
+                    }
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
