@@ -14,7 +14,7 @@ F32 = 0
 BF16 = 1
 SLACK_ROWS = 72
 CHUNK = 2048
-ROW_STORE, ROW_POOL2, ROW_UP2, ROW_PAIRSUM, ROW_UNPOOL = 0, 1, 2, 3, 4
+ROW_STORE, ROW_POOL2, ROW_UP2, ROW_PAIRSUM, ROW_UNPOOL, ROW_LATENT_BWD = 0, 1, 2, 3, 4, 5
 
 
 class Seq(C.Structure):
@@ -26,7 +26,9 @@ class Epilogue(C.Structure):
     _fields_ = [('bias', C.c_void_p), ('relu', C.c_int32), ('row_mode', C.c_int32), ('reshape_w', C.c_int32),
                 ('dst', Seq), ('act', Seq), ('act_rowmul', C.c_int32), ('act_scale', C.c_float),
                 ('sel', C.c_void_p), ('sel_bstride', C.c_int64), ('sel_cp', C.c_int32),
-                ('keep', C.c_void_p), ('keep_scale', C.c_float), ('bias_row_w', C.c_int32)]
+                ('keep', C.c_void_p), ('keep_scale', C.c_float),
+                ('lat_mlv', C.c_void_p), ('lat_eps', C.c_void_p), ('lat_keep', C.c_void_p), ('lat_D', C.c_int32),
+                ('lat_keep_prob', C.c_float), ('lat_std_scale', C.c_float), ('lat_kc', C.c_float), ('bias_row_w', C.c_int32)]
 
 
 class ConvArgs(C.Structure):

@@ -85,7 +85,8 @@ static int dense_params(const c1v_dense_args* a, const char* what, NtParams& p) 
     p = NtParams{};
     p.A = (const char*)a->a; p.a_bstride_b = a->lda * es; p.lda_b = a->lda * es; p.a_off = 0;
     p.W = (const char*)a->w_op; p.ldw_b = a->ldw * es; p.Kb = (int64_t)a->K * es;
-    C1V_REQUIRE(a->epi.row_mode == C1V_ROW_STORE || a->epi.row_mode == C1V_ROW_UNPOOL, "%s: dense epilogue supports STORE / UNPOOL only", what);
+    C1V_REQUIRE(a->epi.row_mode == C1V_ROW_STORE || a->epi.row_mode == C1V_ROW_UNPOOL || a->epi.row_mode == C1V_ROW_LATENT_BWD,
+                "%s: dense epilogue supports STORE / UNPOOL / LATENT_BWD only", what);
     if (a->k_splits > 1) {
         const int64_t kt = c1v_cdiv(p.Kb, 128);
         C1V_REQUIRE(a->k_splits <= kt && a->split_stride > 0, "%s: bad split-K (k_splits=%d, K tiles=%lld)", what, a->k_splits, (long long)kt);

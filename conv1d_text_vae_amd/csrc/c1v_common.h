@@ -96,6 +96,7 @@ struct EpiDev {
     uint8_t* sel; int64_t sel_bstride; int sel_cp;
     const uint8_t* keep; float keep_scale;
     int M, Le, nrows, N;
+    const float* lat_mlv; const float* lat_eps; const uint8_t* lat_keep; int lat_D; float lat_keep_prob, lat_std_scale, lat_kc;
     int bias_row_w;       // c1v_epilogue::bias_row_w
     int fastw;            // 4 / 2: every group address of the epilogue is a multiple of that many elements (vector path); 0: element-wise
 };

@@ -81,9 +81,11 @@ int c1v_fill_epi(const c1v_epilogue& e, EpiDev& d, int M, int Le, int nrows, int
     d.act_cp = e.act.cp; d.act_rowmul = e.act_rowmul > 0 ? e.act_rowmul : 1; d.act_scale = e.act_scale;
     d.sel = e.sel; d.sel_bstride = e.sel_bstride; d.sel_cp = e.sel_cp;
     d.keep = e.keep; d.keep_scale = e.keep_scale; d.bias_row_w = e.bias_row_w;
+    d.lat_mlv = e.lat_mlv; d.lat_eps = e.lat_eps; d.lat_keep = e.lat_keep; d.lat_D = e.lat_D;
+    d.lat_keep_prob = e.lat_keep_prob; d.lat_std_scale = e.lat_std_scale; d.lat_kc = e.lat_kc;
     d.M = M; d.Le = Le; d.nrows = nrows; d.N = N;
     C1V_REQUIRE(e.dst.data != nullptr, "epilogue has no destination");
-    C1V_REQUIRE(e.row_mode >= C1V_ROW_STORE && e.row_mode <= C1V_ROW_UNPOOL, "bad row_mode %d", e.row_mode);
+    C1V_REQUIRE(e.row_mode >= C1V_ROW_STORE && e.row_mode <= C1V_ROW_LATENT_BWD, "bad row_mode %d", e.row_mode);
     C1V_REQUIRE(e.row_mode != C1V_ROW_UNPOOL || e.sel != nullptr, "UNPOOL needs sel");
     C1V_REQUIRE(e.reshape_w <= 0 || (e.row_mode == C1V_ROW_STORE || e.row_mode == C1V_ROW_UNPOOL), "reshape_w only with STORE/UNPOOL");
     C1V_REQUIRE(e.bias_row_w == 0 || (e.reshape_w > 0 && e.bias_row_w > 0 && e.bias_row_w <= e.reshape_w), "bias_row_w %d needs reshape_w >= it", e.bias_row_w);
@@ -103,7 +105,15 @@ int c1v_fill_epi(const c1v_epilogue& e, EpiDev& d, int M, int Le, int nrows, int
             ok = ok && e.sel_bstride % vw == 0 && e.sel_cp % vw == 0 && n_samples * e.sel_bstride + e.sel_cp < (int64_t)1 << 31;
             ok = ok && (e.sel == nullptr || al(e.sel, 1)) && (e.keep == nullptr || al(e.keep, 1));
         }
+        if (e.row_mode == C1V_ROW_LATENT_BWD)
+            ok = ok && vw == 4 && e.lat_D % 4 == 0 && al(e.lat_mlv, 4) && al(e.lat_eps, 4) && (e.lat_keep == nullptr || al(e.lat_keep, 1));
         if (ok) d.fastw = vw;
+    }
+    if (e.row_mode == C1V_ROW_LATENT_BWD) {
+        C1V_REQUIRE(e.lat_mlv && e.lat_eps && e.lat_D == N && e.lat_keep_prob > 0.f, "LATENT_BWD: needs lat_mlv, lat_eps and lat_D == N");
+        C1V_REQUIRE(e.bias == nullptr && !e.relu && e.act.data == nullptr && e.keep == nullptr && e.reshape_w <= 0, "LATENT_BWD: no bias / relu / act / keep / reshape");
+        C1V_REQUIRE(e.dst.cp >= 2 * N, "LATENT_BWD: destination rows must hold 2*lat_D values");
+        C1V_REQUIRE(d.fastw == 4, "LATENT_BWD needs the 4-wide vector epilogue (lat_D %% 4 == 0, 16-byte aligned buffers)");
     }
     if (const char* env = getenv("C1V_EPI_ELEMENTWISE")) if (env[0] == '1') d.fastw = 0;     // diagnostic: force the element-wise path
     if (getenv("C1V_EPI_TRACE")) fprintf(stderr, "c1v epilogue: mode %d M %d N %d reshape_w %d dst_cp %d -> vector width %d\n", e.row_mode, M, N, e.reshape_w, e.dst.cp, d.fastw);

@@ -227,7 +227,8 @@ struct EpiState {
     static constexpr int CH = 4;
     int64_t di[CH];        // destination element index of the group (row 2t for UP2 / UNPOOL)
     int si[CH];            // index of the group's mask bytes (sel / keep)
-    uint4 act[CH];         // raw activation words: bf16 in .x .y, fp32 in .x .. .w
+    uint4 act[CH];         // raw activation words: bf16 in .x .y, fp32 in .x .. .w   (LATENT_BWD: z_mean)
+    uint4 x1[CH], x2[CH];  // LATENT_BWD only: z_log_var and eps of the group
     uint32_t by[CH];       // four mask bytes
     uint32_t flags;        // 4 bits per row: 1 = stored, 2 = UP2: second row fits / PAIRSUM: first member valid, 4 = PAIRSUM: second member valid
     int cnt;               // valid channels of the group (VW = 4: always 4; VW = 2: 2 or 4); 0 = thread idle
@@ -280,7 +281,7 @@ __device__ __forceinline__ void epi_load(const EpiDev& e, const RowDiv& rd, EpiS
     using S = EpiShape<BM, BN, MODE>;
     constexpr bool PAIRS = S::PAIRS;
     constexpr int G = S::G, RPI = S::RPI, CH = S::CH;
-    constexpr bool USE_ACT = MODE != C1V_ROW_UP2 && MODE != C1V_ROW_POOL2;
+    constexpr bool USE_ACT = MODE != C1V_ROW_UP2 && MODE != C1V_ROW_POOL2 && MODE != C1V_ROW_LATENT_BWD;
     const int g = tid % G, r0 = tid / G;
     const int n = n0 + 4 * g;
     st.flags = 0; st.cnt = 0;
@@ -298,7 +299,7 @@ __device__ __forceinline__ void epi_load(const EpiDev& e, const RowDiv& rd, EpiS
         const int t = e.reshape_w > 0 ? tn : (PAIRS ? (u >> 1) : u);
         bool o = m0 + r < e.M;
         uint32_t f = 0;
-        if (MODE == C1V_ROW_STORE) o = o && u < e.nrows && t < e.dst_len;
+        if (MODE == C1V_ROW_STORE || MODE == C1V_ROW_LATENT_BWD) o = o && u < e.nrows && t < e.dst_len;
         else if (MODE == C1V_ROW_UP2) { o = o && u < e.nrows && 2 * t < e.dst_len; f = 2 * t + 1 < e.dst_len ? 2u : 0u; }
         else if (MODE == C1V_ROW_UNPOOL) o = o && u < e.nrows && 2 * t + 1 < e.dst_len;
         else if (MODE == C1V_ROW_POOL2) o = o && t < e.dst_len && u + 1 < e.nrows;
@@ -308,6 +309,16 @@ __device__ __forceinline__ void epi_load(const EpiDev& e, const RowDiv& rd, EpiS
         st.si[jj] = (int)((int64_t)b * e.sel_bstride + (int64_t)t * e.sel_cp + c);
         st.act[jj] = make_uint4(0u, 0u, 0u, 0u);
         st.by[jj] = 0x01010101u;
+        if (MODE == C1V_ROW_LATENT_BWD) {
+            st.x1[jj] = st.act[jj]; st.x2[jj] = st.act[jj];
+            if (o) {                                      // VW == 4: whole 16-byte words of z_mean, z_log_var, eps; 4 mask bytes
+                const int64_t row = (int64_t)b * e.lat_D + c;
+                st.act[jj] = *(const uint4*)(e.lat_mlv + 2 * (int64_t)b * e.lat_D + c);
+                st.x1[jj] = *(const uint4*)(e.lat_mlv + 2 * (int64_t)b * e.lat_D + e.lat_D + c);
+                st.x2[jj] = *(const uint4*)(e.lat_eps + row);
+                if (e.lat_keep) st.by[jj] = *(const uint32_t*)(e.lat_keep + row);
+            }
+        }
         if (o) {
             st.flags |= (1u | f) << (4 * jj);
             if (USE_ACT && e.act)
@@ -323,7 +334,7 @@ __device__ __forceinline__ void epi_finish(const EpiDev& e, const EpiState& st, 
     using S = EpiShape<BM, BN, MODE>;
     constexpr bool PAIRS = S::PAIRS;
     constexpr int G = S::G, RPI = S::RPI, CH = S::CH;
-    constexpr bool USE_ACT = MODE != C1V_ROW_UP2 && MODE != C1V_ROW_POOL2;
+    constexpr bool USE_ACT = MODE != C1V_ROW_UP2 && MODE != C1V_ROW_POOL2 && MODE != C1V_ROW_LATENT_BWD;
     if (st.flags == 0) return;
     const int g = tid % G, r0 = tid / G;
     const int cnt = st.cnt;
@@ -354,7 +365,23 @@ __device__ __forceinline__ void epi_finish(const EpiDev& e, const EpiState& st, 
         }
         const uint32_t by = st.by[jj];
         const int64_t d = st.di[jj];
-        if (MODE == C1V_ROW_STORE) {
+        if (MODE == C1V_ROW_LATENT_BWD) {
+            // c1v_latent_head_bwd on the fly: v = d loss / d zd
+            const uint32_t mw[4] = {st.act[jj].x, st.act[jj].y, st.act[jj].z, st.act[jj].w};
+            const uint32_t lw[4] = {st.x1[jj].x, st.x1[jj].y, st.x1[jj].z, st.x1[jj].w};
+            const uint32_t ew[4] = {st.x2[jj].x, st.x2[jj].y, st.x2[jj].z, st.x2[jj].w};
+            float dm[4], dl[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float dz = v[k];
+                if (e.lat_keep) dz = ((by >> (8 * k)) & 255u) ? dz / e.lat_keep_prob : 0.0f;
+                const float mv = __uint_as_float(mw[k]), l = __uint_as_float(lw[k]);
+                dm[k] = dz + 2.0f * mv * e.lat_kc;
+                dl[k] = dz * __uint_as_float(ew[k]) * e.lat_std_scale * expf(e.lat_std_scale * l) + (expf(l) - 1.0f) * e.lat_kc;
+            }
+            epi_st<VW>(e, d, dm, cnt);
+            epi_st<VW>(e, d + e.lat_D, dl, cnt);
+        } else if (MODE == C1V_ROW_STORE) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 v[k] *= am[k];
@@ -420,6 +447,7 @@ __device__ __forceinline__ void epi_fast_rows(const EpiDev& e, const RowDiv& rd,
         case C1V_ROW_POOL2:   { constexpr int MODE_ = C1V_ROW_POOL2;   constexpr int VW_ = VWV; CALL; } break; \
         case C1V_ROW_UP2:     { constexpr int MODE_ = C1V_ROW_UP2;     constexpr int VW_ = VWV; CALL; } break; \
         case C1V_ROW_PAIRSUM: { constexpr int MODE_ = C1V_ROW_PAIRSUM; constexpr int VW_ = VWV; CALL; } break; \
+        case C1V_ROW_LATENT_BWD: { constexpr int MODE_ = C1V_ROW_LATENT_BWD; constexpr int VW_ = VWV; CALL; } break; \
         default:              { constexpr int MODE_ = C1V_ROW_UNPOOL;  constexpr int VW_ = VWV; CALL; } break; \
     }
 

@@ -357,7 +357,7 @@ class VAEEngine:
              act_rowmul=1, act_scale=1.0, sel=None, sel_bstride=0, sel_cp=0, keep=None, keep_scale=1.0,
              bias_row_w=0) -> L.Epilogue:
         return L.Epilogue(bias, relu, row_mode, reshape_w, dst, act if act is not None else _null_seq(), act_rowmul,
-                          act_scale, sel, sel_bstride, sel_cp, keep, keep_scale, bias_row_w)
+                          act_scale, sel, sel_bstride, sel_cp, keep, keep_scale, bias_row_w=bias_row_w)
 
     def _bias_ptr(self, name: str) -> int:
         return self._pslice(name)
@@ -578,7 +578,17 @@ class VAEEngine:
                                                     self.wop['dec%d_dg' % i].data_ptr(), self.wld['dec%d_dg' % i], C_in, e)), wg)
         wg = dense_wgrad(self.zd.data_ptr(), self.Dp, self.D, self.dDense.t.data_ptr(), self.nd_p, self.nd,
                          'deconv_decoder_dense/kernel', 'deconv_decoder_dense/bias')
-        if not self.frozen:
+        if not self.frozen and self.D % 4 == 0 and os.environ.get('C1V_LATENT_FUSE', '1') == '1':
+            # the gradient of [z_mean | z_log_var] comes straight out of the dense dgrad's epilogue (C1V_ROW_LATENT_BWD):
+            # no dzd round trip, no latent_bwd launch
+            dmlv_seq = L.Seq(self.dmlv.data_ptr(), self.code, B, self.D2p, 0, 1, self.D2p, 2 * self.D)
+            e = self._epi(dmlv_seq, L.ROW_LATENT_BWD)
+            e.lat_mlv, e.lat_eps, e.lat_keep = self.mlv.data_ptr(), self.eps.data_ptr(), self.keep_d.data_ptr()
+            e.lat_D, e.lat_keep_prob, e.lat_std_scale = self.D, KEEP_PROB, self.std_scale
+            e.lat_kc = 1.0 / (self.D * self.Bg)
+            stage(('c1v_dense_dgrad', L.DenseArgs(self.dDense.t.data_ptr(), self.code, B, self.nd_p, self.nd_p,
+                                                  self.wop['dense_dg'].data_ptr(), self.wld['dense_dg'], self.D, e)), wg)
+        elif not self.frozen:
             dzd_seq = L.Seq(self.dzd.data_ptr(), L.F32, B, self.D, 0, 1, self.D, self.D)
             stage(('c1v_dense_dgrad', L.DenseArgs(self.dDense.t.data_ptr(), self.code, B, self.nd_p, self.nd_p,
                                                   self.wop['dense_dg'].data_ptr(), self.wld['dense_dg'], self.D,

@@ -51,6 +51,10 @@ typedef struct c1v_seq {
 #define C1V_ROW_UP2     2   /* UpSampling1D(2)+Cropping1D: row u -> 2u, 2u+1 (< dst.len) (a6)  */
 #define C1V_ROW_PAIRSUM 3   /* backward of UP2: rows (2i,2i+1) summed -> i                     */
 #define C1V_ROW_UNPOOL  4   /* backward of POOL2: row u -> 2u+sel (other row <- 0)             */
+#define C1V_ROW_LATENT_BWD 5 /* dense dgrad straight into the gradient of [z_mean | z_log_var]: the GEMM value (b, d) is
+                                d loss / d zd; the epilogue applies c1v_latent_head_bwd's arithmetic (dropout mask, sampling
+                                and KL terms, see the lat_* fields) and stores dst(b, d) and dst(b, lat_D + d).  Vector
+                                epilogue only (lat_D a multiple of 4, 16-byte aligned buffers). */
 
 /* Generic fused epilogue applied by conv / dense kernels to each accumulator element (u, n) of sample b:
  *   v += bias[n]; v = relu(v) if relu;
@@ -73,6 +77,10 @@ typedef struct c1v_epilogue {
     int32_t        sel_cp;
     const uint8_t* keep;        /* dropout keep mask, same indexing as sel */
     float          keep_scale;
+    /* C1V_ROW_LATENT_BWD only: mlv [B][2*lat_D] f32, eps [B][lat_D] f32, keep mask [B][lat_D] or NULL, and the scalars of
+       c1v_latent_args (lat_kc = 1 / (lat_D * B_global)) */
+    const float*   lat_mlv; const float* lat_eps; const uint8_t* lat_keep;
+    int32_t        lat_D; float lat_keep_prob, lat_std_scale, lat_kc;
     int32_t        bias_row_w;  /* with reshape_w: the GEMM was laid out with every (t, .) row padded from bias_row_w up to
                                    reshape_w channels (zero weight rows) so that the vector epilogue applies to widths that
                                    are not multiples of 4; bias index = t*bias_row_w + c, pad channels get 0.  0 = no padding */
