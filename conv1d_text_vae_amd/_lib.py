@@ -14,6 +14,7 @@ F32 = 0
 BF16 = 1
 SLACK_ROWS = 72
 CHUNK = 2048
+PACK_TILE = 64          # C1V_PACK_TILE
 ROW_STORE, ROW_POOL2, ROW_UP2, ROW_PAIRSUM, ROW_UNPOOL, ROW_LATENT_BWD = 0, 1, 2, 3, 4, 5
 
 

@@ -131,46 +131,52 @@ extern "C" int c1v_gather_input(const c1v_gather_input_args* a, void* stream) {
 // ------------------------------------------------------------------------------------------------------
 // weight operand copies (descriptor table on the device; blockIdx.y = descriptor)
 // ------------------------------------------------------------------------------------------------------
+constexpr int PW_TS = C1V_PACK_TILE;                 // tile edge of the weight packer (include/c1dvae.h)
 __device__ __forceinline__ void pack_weights_body(const c1v_pack_desc* __restrict__ descs, int n_desc, int blk) {
-    // One block = one 32(c) x 32(n) tile of one tap of one descriptor, transposed through LDS so that BOTH the fp32 read
-    // (along whichever of n / c is contiguous in the Keras layout) and the operand write (along c) are whole row
-    // segments.  Blocks are dealt to descriptors by `first_block`; within a descriptor the tile index enumerates
-    // (tap, c tile, n tile).
-    __shared__ float tile[32][33];
+    // One block = one 64(c) x 64(n) tile of one tap of one descriptor, transposed through LDS so that BOTH the fp32 read
+    // (along whichever of n / c is contiguous in the Keras layout: 256-byte row segments) and the operand write (along
+    // c) are whole row segments.  Blocks are dealt to descriptors by `first_block`; within a descriptor the tile index
+    // enumerates (tap, c tile, n tile).  Loads are unconditional (clamped index, value masked): a load under a bounds
+    // test compiles to a branch with its own wait.
+    __shared__ float tile[PW_TS][PW_TS + 1];
     const int di = find_desc(descs, n_desc, blk);
     const c1v_pack_desc d = descs[di];
-    const int tc = (d.c_count + 31) >> 5, tn = (d.n_count + 31) >> 5;
+    const int tc = (d.c_count + PW_TS - 1) / PW_TS, tn = (d.n_count + PW_TS - 1) / PW_TS;
     int bi = blk - d.first_block;
     const int tn_i = bi % tn; bi /= tn;
     const int tc_i = bi % tc;
     const int tap = bi / tc;
     if (tap >= d.taps) return;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 8
-    const int c0 = tc_i * 32, n0 = tn_i * 32;
+    const int tx = threadIdx.x & (PW_TS - 1), ty = threadIdx.x / PW_TS;          // 64 x 4
+    constexpr int RPT = PW_TS / (256 / PW_TS);                                   // rows per thread
+    const int c0 = tc_i * PW_TS, n0 = tn_i * PW_TS;
     const float* src = d.src + (int64_t)tap * d.s_tap;
+    float v[RPT];
     if (d.s_n <= d.s_c) {
         // n is the fast axis of the source: read rows of n, tile[c][n]
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int c = c0 + ty + 8 * k, n = n0 + tx;
-            const float t2 = src[(int64_t)(c < d.c_count ? c : d.c_count - 1) * d.s_c + (int64_t)(n < d.n_count ? n : d.n_count - 1) * d.s_n];
-            tile[ty + 8 * k][tx] = (c < d.c_count && n < d.n_count) ? t2 : 0.0f;
+        for (int k = 0; k < RPT; ++k) {
+            const int c = c0 + ty + (256 / PW_TS) * k, n = n0 + tx;
+            v[k] = src[(int64_t)(c < d.c_count ? c : d.c_count - 1) * d.s_c + (int64_t)(n < d.n_count ? n : d.n_count - 1) * d.s_n];
         }
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) tile[ty + (256 / PW_TS) * k][tx] = v[k];
     } else {
         // c is the fast axis of the source: read rows of c
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int n = n0 + ty + 8 * k, c = c0 + tx;
-            const float t2 = src[(int64_t)(c < d.c_count ? c : d.c_count - 1) * d.s_c + (int64_t)(n < d.n_count ? n : d.n_count - 1) * d.s_n];
-            tile[tx][ty + 8 * k] = (c < d.c_count && n < d.n_count) ? t2 : 0.0f;
+        for (int k = 0; k < RPT; ++k) {
+            const int n = n0 + ty + (256 / PW_TS) * k, c = c0 + tx;
+            v[k] = src[(int64_t)(c < d.c_count ? c : d.c_count - 1) * d.s_c + (int64_t)(n < d.n_count ? n : d.n_count - 1) * d.s_n];
         }
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) tile[tx][ty + (256 / PW_TS) * k] = v[k];
     }
     __syncthreads();
     const int tp = d.flip ? d.taps - 1 - tap : tap;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int n = n0 + ty + 8 * k, c = c0 + tx;
-        if (c < d.c_count && n < d.n_count) store_any(d.dst, d.dtype, (int64_t)n * d.ldk + (int64_t)tp * d.cp + c, tile[tx][ty + 8 * k]);
+    for (int k = 0; k < RPT; ++k) {
+        const int n = n0 + ty + (256 / PW_TS) * k, c = c0 + tx;
+        if (c < d.c_count && n < d.n_count) store_any(d.dst, d.dtype, (int64_t)n * d.ldk + (int64_t)tp * d.cp + c, tile[tx][ty + (256 / PW_TS) * k]);
     }
 }
 

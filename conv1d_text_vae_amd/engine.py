@@ -302,7 +302,7 @@ class VAEEngine:
             for gi in range(n_groups):
                 descs.append(L.PackDesc(self._pslice(src_name) + 4 * gi * n_count * s_n, t.data_ptr() + esz * gi * group_pad * ldk,
                                         self.code, n_count, taps, c_count, cp, flip, ldk, s_tap, s_c, s_n, nblk[0], 0))
-                nblk[0] += taps * ((c_count + 31) // 32) * ((n_count + 31) // 32)
+                nblk[0] += taps * ((c_count + L.PACK_TILE - 1) // L.PACK_TILE) * ((n_count + L.PACK_TILE - 1) // L.PACK_TILE)
 
         c_in = g.input_vector_size
         for l, f in enumerate(g.n_filters):

@@ -176,11 +176,12 @@ int c1v_colsum(const c1v_colsum_args*, void* stream);
 /* ---- operand copies of the fp32 master weights ------------------------------------------------------------
  * dst[n*ldk + tap'*cp + c] = src[tap*s_tap + c*s_c + n*s_n],  tap' = flip ? taps-1-tap : tap,
  * for n < n_count, tap < taps, c < c_count.  Padding entries of dst are never written (stay zero). */
+#define C1V_PACK_TILE 64   /* c1v_pack_weights: one workgroup per C1V_PACK_TILE x C1V_PACK_TILE tile of one tap */
 typedef struct c1v_pack_desc {
     const float* src; void* dst; int32_t dtype;
     int32_t n_count, taps, c_count, cp, flip;
     int64_t ldk, s_tap, s_c, s_n;
-    int32_t first_block, pad;   /* descriptor i owns blocks [first_block_i, first_block_{i+1}): taps * ceil(c_count/32) * ceil(n_count/32)
+    int32_t first_block, pad;   /* descriptor i owns blocks [first_block_i, first_block_{i+1}): taps * ceil(c_count/C1V_PACK_TILE) * ceil(n_count/C1V_PACK_TILE)
                                  * each (one block = one 32x32 tile of one tap, transposed through LDS) */
 } c1v_pack_desc;
 #define C1V_CHUNK 2048          /* elements handled by one block of the descriptor-table kernels */
