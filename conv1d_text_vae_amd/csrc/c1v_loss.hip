@@ -202,13 +202,11 @@ void vocab_stream_kernel(const bf16_raw* __restrict__ yhat, int M, const bf16_ra
     //   * nothing separates the end of GEMM2(t) from GEMM1(t+1), so the first fragments of tile t+1 are fetched behind the
     //     last GEMM2 batch of tile t (with the barrier at the end of the tile every tile began with an exposed LDS round
     //     trip and a barrier skew: GEMM1's first half took 1450 cycles against 900 for the second, exp2 work included).
-    // The other modes (no GEMM2) keep the barrier at the end of the tile.
+    // The other modes (no GEMM2) put the same single barrier between the two halves (nb = 0 | nb = 1) of GEMM1.
     uint4 a1[2][G1];
-    if constexpr (MODE == VS_ACCUM) {
-        if (t_begin < t_end) {
+    if (t_begin < t_end) {
 #pragma unroll
-            for (int j = 0; j < G1; ++j) a1[0][j] = *(const uint4*)(smem + vs_off<CB>(l31, 2 * j + h));
-        }
+        for (int j = 0; j < G1; ++j) a1[0][j] = *(const uint4*)(smem + vs_off<CB>(l31, 2 * j + h));
     }
     for (int t = t_begin; t < t_end; ++t) {
         VS_T(7);
@@ -267,10 +265,6 @@ void vocab_stream_kernel(const bf16_raw* __restrict__ yhat, int M, const bf16_ra
         };
 
         uint4 a2[3][CG * 2];
-        if constexpr (MODE != VS_ACCUM) {
-#pragma unroll
-            for (int j = 0; j < G1; ++j) a1[0][j] = ld1(0, j);
-        }
 #pragma unroll
         for (int q = 0; q < Q1; ++q) {
             const int nb = q / NB1, s0 = (q % NB1) * G1;
@@ -295,18 +289,23 @@ void vocab_stream_kernel(const bf16_raw* __restrict__ yhat, int M, const bf16_ra
                 S[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a1[q & 1][j]), yf[s0 + j], S[nb], 0, 0, 0);
             }
 #if !(defined(VS_ABLATE) && (VS_ABLATE & 8))
-            // the request for tile t+2 goes out in the shadow of the nb=0 MFMAs (its stage was released by the barrier
-            // that ended tile t-1), a few pieces per batch
-            // Each wave sends ALL its pieces behind ONE batch, a different batch per wave: a request occupies the CU's
-            // address path for ~16 cycles and blocks the issuing wave meanwhile; when the four waves issued a few pieces
-            // each behind the same batches they queued behind one another (measured: ~700 cycles per tile and wave).
-            if (MODE != VS_ACCUM && (Q1 >= 8 ? q == 2 * wave : (nb == 0)) && more) {
-                if constexpr (Q1 >= 8) {
+            if constexpr (MODE != VS_ACCUM) {
+                // GEMM1-only modes: barrier behind the nb = 0 half, request for tile t+2 behind the nb = 1 batches (one
+                // wave per batch where there are enough batches), first fragments of tile t+1 behind the last batch
+                if (q == NB1 - 1) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    VS_T(4);
+                    __syncthreads();
+                    VS_T(5);
+                }
+                if ((NB1 >= 4 ? q == NB1 + wave : q == NB1) && more) {
 #pragma unroll
                     for (int i = 0; i < Cfg::PPW; ++i) stage_piece(t + 2, (stage + 2) % VS_STAGES, i);
-                } else {
+                }
+                if (q == Q1 - 1 && t + 1 < t_end) {
+                    const char* swn1 = smem + ((t + 1 - t_begin) % VS_STAGES) * Cfg::STAGE;
 #pragma unroll
-                    for (int i = q * Cfg::PPW / NB1; i < (q + 1) * Cfg::PPW / NB1; ++i) stage_piece(t + 2, (stage + 2) % VS_STAGES, i);
+                    for (int j = 0; j < G1; ++j) a1[0][j] = *(const uint4*)(swn1 + vs_off<CB>(l31, 2 * j + h));
                 }
             }
 #endif
@@ -376,16 +375,6 @@ void vocab_stream_kernel(const bf16_raw* __restrict__ yhat, int M, const bf16_ra
                 if (q == Q2 - 1) VS_T(3);
             }
         }
-#if !(defined(VS_ABLATE) && (VS_ABLATE & 8))
-        if constexpr (MODE != VS_ACCUM) {
-            // tile t+1 must have landed; tile t+2's request (the youngest PPW loads of this wave) stays in flight
-            if (t + 2 < t_end) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Cfg::PPW) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            VS_T(4);
-            __syncthreads();
-            VS_T(5);
-        }
-#endif
     }
 #ifdef VS_STAMP
     unsigned long long tloop;
