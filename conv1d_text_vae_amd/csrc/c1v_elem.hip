@@ -350,37 +350,59 @@ __global__ __launch_bounds__(256) void grad_finalize_kernel(const c1v_seg_desc* 
     // slabs, segment offsets and counts are multiples of 4 floats except for a tail: float4 body, scalar tail
     const bool vec = (d.count % 4 == 0) && (d.slab_stride % 4 == 0) && (d.rep_stride % 4 == 0) && (d.offset % 4 == 0) &&
                      (((uintptr_t)d.slab) % 16 == 0);
+    constexpr int KI = C1V_CHUNK / 1024;               // float4 groups per thread
+    if (vec) {
+        // All KI groups of a thread advance together through the slabs, four slabs per round: 4 KI independent 16-byte
+        // requests are in flight per round (the kernel is latency-bound: one group at a time meant KI x splits/4 serial
+        // round trips for the segments with many wgrad splits).  Slab order is (split, rep): the sum is reproducible.
+        int64_t idx[KI];
+        bool in[KI];
+        float4 g[KI];
 #pragma unroll
-    for (int k = 0; k < C1V_CHUNK / 1024; ++k) {
-        const int64_t i = base + (int64_t)(k * 256 + threadIdx.x) * 4;
-        if (i >= d.count) continue;
-        if (vec) {
-            float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (!d.frozen) {
-                // slabs in (split, rep) order, four independent requests per round, no integer division in the loop
-                const int ns = d.splits * d.reps;
-                int64_t off = 0;
-                int sp = 0, r = 0;
-                for (int s0 = 0; s0 < ns; s0 += 4) {
-                    int64_t o[4];
+        for (int k = 0; k < KI; ++k) {
+            idx[k] = base + (int64_t)(k * 256 + threadIdx.x) * 4;
+            in[k] = idx[k] < d.count;
+            if (!in[k]) idx[k] = 0;                    // clamped: loads stay unconditional, results are dropped
+            g[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        if (!d.frozen) {
+            const int ns = d.splits * d.reps;
+            int64_t off = 0;
+            int sp = 0, r = 0;
+            for (int s0 = 0; s0 < ns; s0 += 4) {
+                int64_t o[4];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        o[q] = off;
-                        if (s0 + q + 1 < ns) {
-                            ++r; off += d.rep_stride;
-                            if (r == d.reps) { r = 0; ++sp; off = (int64_t)sp * d.slab_stride; }
-                        }
+                for (int q = 0; q < 4; ++q) {
+                    o[q] = off;
+                    if (s0 + q + 1 < ns) {
+                        ++r; off += d.rep_stride;
+                        if (r == d.reps) { r = 0; ++sp; off = (int64_t)sp * d.slab_stride; }
                     }
-                    float4 v[4];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) v[q] = *(const float4*)(d.slab + o[q] + i);
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) if (s0 + q < ns) { g.x += v[q].x; g.y += v[q].y; g.z += v[q].z; g.w += v[q].w; }
                 }
+                float4 v[4][KI];
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int k = 0; k < KI; ++k) v[q][k] = *(const float4*)(d.slab + o[q] + idx[k]);
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (s0 + q < ns) {
+#pragma unroll
+                        for (int k = 0; k < KI; ++k) { g[k].x += v[q][k].x; g[k].y += v[q][k].y; g[k].z += v[q][k].z; g[k].w += v[q][k].w; }
+                    }
             }
-            *(float4*)(grad + d.offset + i) = g;
-            sq += (g.x * g.x + g.y * g.y) + (g.z * g.z + g.w * g.w);
-        } else {
+        }
+#pragma unroll
+        for (int k = 0; k < KI; ++k)
+            if (in[k]) {
+                *(float4*)(grad + d.offset + idx[k]) = g[k];
+                sq += (g[k].x * g[k].x + g[k].y * g[k].y) + (g[k].z * g[k].z + g[k].w * g[k].w);
+            }
+    } else {
+#pragma unroll
+        for (int k = 0; k < KI; ++k) {
+            const int64_t i = base + (int64_t)(k * 256 + threadIdx.x) * 4;
+            if (i >= d.count) continue;
             for (int e = 0; e < 4 && i + e < d.count; ++e) {
                 float g = 0.f;
                 if (!d.frozen)

@@ -3,7 +3,7 @@
 #include "c1v_common.h"
 
 // loss scalars (single block, deterministic order)
-constexpr int LR_CAP = 4096;                       // row values staged per pass
+constexpr int LR_CAP = 8448;                       // row values staged per pass (256 samples of 32 steps at pitch 33)
 // (one workgroup of any whole number of waves <= 16; also run as an extra block of grad_finalize)
 __device__ __forceinline__ void loss_reduce_body(const float* __restrict__ xent_rows, const int* __restrict__ ids,
                                                  const float* __restrict__ kl_b, int B, int T_len, int B_global,
@@ -11,7 +11,8 @@ __device__ __forceinline__ void loss_reduce_body(const float* __restrict__ xent_
     // Pass structure: all threads stage the per-step values of S = LR_CAP / (T + 1) samples in LDS with independent,
     // coalesced loads (a wave-per-sample loop serialised one global-load latency per sample: 16 us at B = 256), then
     // thread i sums the T steps of sample i in step order (pitch T + 1: conflict-free).  Every sum has a fixed order.
-    __shared__ float vx[LR_CAP], vc[LR_CAP];
+    __shared__ float vx[LR_CAP];
+    __shared__ uint8_t vc[LR_CAP];
     __shared__ float sx[16], sk[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x, nwave = nthr >> 6;
     float ax = 0.f, ak = 0.f;
@@ -25,7 +26,7 @@ __device__ __forceinline__ void loss_reduce_body(const float* __restrict__ xent_
             const bool vec = (n & 3) == 0 && (((((uintptr_t)xr) | ((uintptr_t)ir)) & 15) == 0);
             if (vec) {
                 // 16-byte words: four times fewer (independent) requests per thread
-#pragma unroll 4
+#pragma unroll 8
                 for (int i4 = tid; i4 < (n >> 2); i4 += nthr) {
                     const float4 xv = *(const float4*)(xr + 4 * i4);
                     const int4 iv = *(const int4*)(ir + 4 * i4);
@@ -37,7 +38,7 @@ __device__ __forceinline__ void loss_reduce_body(const float* __restrict__ xent_
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         vx[bl * pitch + t] = xs[k];
-                        vc[bl * pitch + t] = is[k] >= 0 ? 1.f : 0.f;
+                        vc[bl * pitch + t] = is[k] >= 0 ? 1 : 0;
                         if (++t == T_len) { t = 0; ++bl; }
                     }
                 }
@@ -48,13 +49,13 @@ __device__ __forceinline__ void loss_reduce_body(const float* __restrict__ xent_
                     int t = i - bl * T_len;
                     if (t < 0) { --bl; t += T_len; } else if (t >= T_len) { ++bl; t -= T_len; }
                     vx[bl * pitch + t] = xr[i];
-                    vc[bl * pitch + t] = ir[i] >= 0 ? 1.f : 0.f;
+                    vc[bl * pitch + t] = ir[i] >= 0 ? 1 : 0;
                 }
             }
             __syncthreads();
             for (int bl = tid; bl < ns; bl += nthr) {
                 float s = 0.f, c = 0.f;
-                for (int t = 0; t < T_len; ++t) { s += vx[bl * pitch + t]; c += vc[bl * pitch + t]; }
+                for (int t = 0; t < T_len; ++t) { s += vx[bl * pitch + t]; c += (float)vc[bl * pitch + t]; }
                 const float xb = s / c;
                 if (xent_b) xent_b[base + bl] = xb;
                 ax += xb;
