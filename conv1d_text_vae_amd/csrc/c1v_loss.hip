@@ -102,13 +102,18 @@ template <int CB> struct VsCfg {
 // byte offset of 16-byte chunk `ch` of row r inside a tile image (chunk index XOR-swizzled in its low 2 bits)
 template <int CB> __device__ __forceinline__ int vs_off(int r, int ch) { return r * VsCfg<CB>::PITCH + ((ch ^ ((r >> 2) & 3)) << 4); }
 
-template <int CB, int MODE>
+template <int CB, int MODE, int MB>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void vocab_stream_kernel(const bf16_raw* __restrict__ yhat, int M, const bf16_raw* __restrict__ w, int N, int n_base,
                          int tiles_total, int tiles_per_split, float* __restrict__ ut, int m_pad, int ones_col,
                          float* __restrict__ part_score, int* __restrict__ part_idx, const int* __restrict__ ctl) {
     using Cfg = VsCfg<CB>;
     constexpr int KS = CB * 2;                     // 16-wide k steps of GEMM1
+    // Sample rows per wave = 32 MB.  MB = 1 with the U accumulators of ACCUM mode (160 registers); the GEMM1-only modes also
+    // come with MB = 2, where every vocabulary fragment read from LDS feeds two MFMAs (LDS bandwidth co-limits the kernel:
+    // all four waves read the whole tile) -- used when there are enough rows to fill the chip with 256-row workgroups
+    static_assert(MB == 1 || MODE != VS_ACCUM, "ACCUM has no registers for a second m-block");
+    constexpr int WG_ROWS = VS_BM * MB;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -119,10 +124,10 @@ void vocab_stream_kernel(const bf16_raw* __restrict__ yhat, int M, const bf16_ra
         const int live = ctl[0], splits = ctl[2];
         const int item = blockIdx.x + gridDim.x * blockIdx.y;
         bx = item / splits; split = item - bx * splits;
-        if (bx * VS_BM >= live) return;             // whole workgroup, before any barrier
+        if (bx * WG_ROWS >= live) return;           // whole workgroup, before any barrier
         M = live; tiles_per_split = ctl[3];
     }
-    const int m_row = bx * VS_BM + wave * 32 + l31;
+    const int m_row0 = bx * WG_ROWS + wave * 32 * MB + l31;      // this lane's row of m-block 0 (m-block mb: + 32 mb)
     const int t_begin = split * tiles_per_split;
     int t_end = t_begin + tiles_per_split;
     if (t_end > tiles_total) t_end = tiles_total;
@@ -153,13 +158,15 @@ void vocab_stream_kernel(const bf16_raw* __restrict__ yhat, int M, const bf16_ra
     if (t_begin + 1 < t_end) stage_tile(t_begin + 1, 1);
 
     // this wave's 32 sample rows as MFMA B operands: B[k = 8h + j][col = l31] = yhat[m_row][16 s + 8h + j]
-    bf16x8_t yf[KS];
-    {
+    bf16x8_t yf[MB][KS];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+        const int m_row = m_row0 + 32 * mb;
         const uint4* yp = (const uint4*)(yhat + (int64_t)(m_row < M ? m_row : 0) * Cfg::KP) + h;
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             uint4 v = (m_row < M) ? yp[2 * s] : make_uint4(0, 0, 0, 0);
-            yf[s] = __builtin_bit_cast(bf16x8_t, v);
+            yf[mb][s] = __builtin_bit_cast(bf16x8_t, v);
         }
     }
 
@@ -168,9 +175,11 @@ void vocab_stream_kernel(const bf16_raw* __restrict__ yhat, int M, const bf16_ra
     for (int c = 0; c < (MODE == VS_ACCUM ? CB : 1); ++c)
 #pragma unroll
         for (int r = 0; r < 16; ++r) U[c][r] = 0.f;
-    float sumexp = 0.f;
-    float best = -3.0e38f;
-    int best_idx = 0x7fffffff;
+    float sumexp[MB];
+    float best[MB];
+    int best_idx[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) { sumexp[mb] = 0.f; best[mb] = -3.0e38f; best_idx[mb] = 0x7fffffff; }
 
     // Both requests and the yf loads (one-time cost).  The BUILTIN form on purpose: the compiler's own bookkeeping must
     // see that the yf loads are complete, or it keeps a `vmcnt(0)` in front of the first MFMA of EVERY tile (an asm wait
@@ -233,33 +242,37 @@ void vocab_stream_kernel(const bf16_raw* __restrict__ yhat, int M, const bf16_ra
                               __builtin_bit_cast(uint2, hi).x, __builtin_bit_cast(uint2, hi).y);
         };
 
-        f32x16_t S[2];
+        f32x16_t S[MB][2];
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb)
+        for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) S[nb][r] = 0.f;
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) S[mb][nb][r] = 0.f;
 
         // VALU stage on accumulator regs [r0, r1) of block nb: exp2 (+ tail mask) / running sum / running arg-max
         auto post = [&](int nb, int r0, int r1) {
 #pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
             for (int r = r0; r < r1; ++r) {
                 if constexpr (MODE == VS_ARGMAX) {
                     const int n = n0 + nb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    const float v = S[nb][r];
-                    if (n < N && v > best) { best = v; best_idx = n; }
+                    const float v = S[mb][nb][r];
+                    if (n < N && v > best[mb]) { best[mb] = v; best_idx[mb] = n; }
                 } else {
 #if defined(VS_ABLATE) && (VS_ABLATE & 1)
-                    float e = S[nb][r];
+                    float e = S[mb][nb][r];
 #else
-                    float e = __builtin_amdgcn_exp2f(S[nb][r]);
+                    float e = __builtin_amdgcn_exp2f(S[mb][nb][r]);
 #endif
                     if constexpr (MODE == VS_SUMEXP) {
                         // (ACCUM needs no tail mask: rows >= N of W are all-zero, ones column included, so whatever
                         // exp2 gives for them is multiplied by zero in GEMM2)
                         if (tail) { const int n = n0 + nb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h; if (n >= N) e = 0.f; }
-                        sumexp += e;
+                        sumexp[mb] += e;
                     }
-                    S[nb][r] = e;
+                    S[mb][nb][r] = e;
                 }
             }
         };
@@ -286,7 +299,11 @@ void vocab_stream_kernel(const bf16_raw* __restrict__ yhat, int M, const bf16_ra
 #if defined(VS_ABLATE) && (VS_ABLATE & 4)
                 if (j == 0 && s0 == 0)
 #endif
-                S[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a1[q & 1][j]), yf[s0 + j], S[nb], 0, 0, 0);
+                {
+#pragma unroll
+                    for (int mb = 0; mb < MB; ++mb)
+                        S[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a1[q & 1][j]), yf[mb][s0 + j], S[mb][nb], 0, 0, 0);
+                }
             }
 #if !(defined(VS_ABLATE) && (VS_ABLATE & 8))
             if constexpr (MODE != VS_ACCUM) {
@@ -322,7 +339,7 @@ void vocab_stream_kernel(const bf16_raw* __restrict__ yhat, int M, const bf16_ra
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) pf[0][ks][j] = (__bf16)S[0][8 * ks + j];
+                for (int j = 0; j < 8; ++j) pf[0][ks][j] = (__bf16)S[0][0][8 * ks + j];
 #if !(defined(VS_ABLATE) && (VS_ABLATE & 8))
             // the tile's only barrier: tile t+1 (this wave's pieces: everything it has in flight) is in LDS, tile t-1 is dead
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -345,7 +362,7 @@ void vocab_stream_kernel(const bf16_raw* __restrict__ yhat, int M, const bf16_ra
 #pragma unroll
                     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) pf[1][ks][j] = (__bf16)S[1][8 * ks + j];
+                        for (int j = 0; j < 8; ++j) pf[1][ks][j] = (__bf16)S[0][1][8 * ks + j];
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -381,7 +398,7 @@ void vocab_stream_kernel(const bf16_raw* __restrict__ yhat, int M, const bf16_ra
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tloop) :: "memory");
 #endif
 
-    const int m_out = bx * VS_BM + wave * 32 + l31;
+    const int m_out = m_row0;
     if constexpr (MODE == VS_ACCUM) {
         // U^T[c][m] sits with m on the lane; the consumer wants rows of U.  Transpose one 32x32 block at a time through
         // this wave's private 4.5 KB of LDS (the W stages are dead after the loop's last barrier) and store 128-byte
@@ -402,15 +419,23 @@ void vocab_stream_kernel(const bf16_raw* __restrict__ yhat, int M, const bf16_ra
             }
         }
     } else if constexpr (MODE == VS_SUMEXP) {
-        sumexp += __shfl_xor(sumexp, 32, 64);
-        if (h == 0) ut[((int64_t)split * m_pad + m_out) * Cfg::KP + ones_col] = sumexp;
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+            const float se = sumexp[mb] + __shfl_xor(sumexp[mb], 32, 64);
+            if (h == 0 && m_out + 32 * mb < m_pad) ut[((int64_t)split * m_pad + m_out + 32 * mb) * Cfg::KP + ones_col] = se;
+        }
     } else {
-        const float ob = __shfl_xor(best, 32, 64);
-        const int oi = __shfl_xor(best_idx, 32, 64);
-        if (ob > best || (ob == best && oi < best_idx)) { best = ob; best_idx = oi; }
-        if (h == 0) {
-            part_score[(int64_t)split * m_pad + m_out] = best;
-            part_idx[(int64_t)split * m_pad + m_out] = best_idx == 0x7fffffff ? 0x7fffffff : best_idx + n_base;
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+            float bv = best[mb];
+            int bi = best_idx[mb];
+            const float ob = __shfl_xor(bv, 32, 64);
+            const int oi = __shfl_xor(bi, 32, 64);
+            if (ob > bv || (ob == bv && oi < bi)) { bv = ob; bi = oi; }
+            if (h == 0 && m_out + 32 * mb < m_pad) {
+                part_score[(int64_t)split * m_pad + m_out + 32 * mb] = bv;
+                part_idx[(int64_t)split * m_pad + m_out + 32 * mb] = bi == 0x7fffffff ? 0x7fffffff : bi + n_base;
+            }
         }
     }
 #ifdef VS_STAMP
@@ -778,18 +803,29 @@ extern "C" int c1v_l2norm_rows(const c1v_l2norm_args* a, void* stream) {
     return 0;
 }
 
-template <int CB, int MODE>
-static int launch_vs(const bf16_raw* yhat, int M, const bf16_raw* w, int N, int n_base, int splits, float* ut, int m_pad, int ones_col,
-                     float* ps, int* pi, const int* ctl, hipStream_t st) {
+template <int CB, int MODE, int MB>
+static int launch_vs_mb(const bf16_raw* yhat, int M, const bf16_raw* w, int N, int n_base, int splits, float* ut, int m_pad, int ones_col,
+                        float* ps, int* pi, const int* ctl, hipStream_t st) {
     using Cfg = VsCfg<CB>;
-    static bool once = (hipFuncSetAttribute((const void*)vocab_stream_kernel<CB, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, VS_STAGES * Cfg::STAGE), true);
+    static bool once = (hipFuncSetAttribute((const void*)vocab_stream_kernel<CB, MODE, MB>, hipFuncAttributeMaxDynamicSharedMemorySize, VS_STAGES * Cfg::STAGE), true);
     (void)once;
     const int tiles_total = (int)c1v_cdiv(N, VS_BN);
     const int tps = (int)c1v_cdiv(tiles_total, splits);
-    dim3 grid((unsigned)(m_pad / VS_BM), (unsigned)splits);
-    hipLaunchKernelGGL((vocab_stream_kernel<CB, MODE>), grid, dim3(256), VS_STAGES * Cfg::STAGE, st, yhat, M, w, N, n_base, tiles_total, tps, ut, m_pad, ones_col, ps, pi, ctl);
+    dim3 grid((unsigned)c1v_cdiv(m_pad, VS_BM * MB), (unsigned)splits);
+    hipLaunchKernelGGL((vocab_stream_kernel<CB, MODE, MB>), grid, dim3(256), VS_STAGES * Cfg::STAGE, st, yhat, M, w, N, n_base, tiles_total, tps, ut, m_pad, ones_col, ps, pi, ctl);
     C1V_LAUNCH_CHECK();
     return 0;
+}
+
+template <int CB, int MODE>
+static int launch_vs(const bf16_raw* yhat, int M, const bf16_raw* w, int N, int n_base, int splits, float* ut, int m_pad, int ones_col,
+                     float* ps, int* pi, const int* ctl, hipStream_t st) {
+    if constexpr (MODE != VS_ACCUM) {
+        // 256-row workgroups when they still fill the chip (and the grid is not a device-dealt pool)
+        if (ctl == nullptr && c1v_cdiv(m_pad, 2 * VS_BM) * splits >= 256)
+            return launch_vs_mb<CB, MODE, 2>(yhat, M, w, N, n_base, splits, ut, m_pad, ones_col, ps, pi, ctl, st);
+    }
+    return launch_vs_mb<CB, MODE, 1>(yhat, M, w, N, n_base, splits, ut, m_pad, ones_col, ps, pi, ctl, st);
 }
 
 template <int MODE>

@@ -265,6 +265,21 @@ def test_eval_loss_parity(dtype):
     assert abs(eng.loss() - ref) < (1e-4 if dtype == 'f32' else 1e-2) * max(1.0, abs(ref))
 
 
+def test_eval_loss_all_rows_with_256_row_workgroups(monkeypatch):
+    """Validation loss over ALL rows (live-row compaction off) of a batch large enough for the 64-rows-per-wave variant of
+    the GEMM1-only stream kernel (SUMEXP mode; the arg-max mode of that variant is pinned by the C3 self-retrieval test)."""
+    monkeypatch.setenv('C1V_LIVE_ROWS', '0')
+    c = CASES['big128']
+    og, params, Wv, x, ids, eps, mask_e, mask_d = make_case(c, seed=6)
+    p64 = {k: v.astype(np.float64) for k, v in params.items()}
+    ref = O.eval_loss(og, p64, Wv.astype(np.float64), x.astype(np.float64), ids, eps.astype(np.float64))
+    eng = build_engine(c, og, params, Wv, 'bf16')
+    assert not eng.compact and (eng.m_pad // 256) * eng.x_splits >= 256
+    load_fixed(eng, x, ids, eps, mask_e, mask_d)
+    eng.eval_step(use_graph=False, fixed_rng=True)
+    assert abs(eng.loss() - ref) < 1e-2 * max(1.0, abs(ref))
+
+
 def test_frozen_encoder_keeps_encoder_weights():
     engine, geometry = _engine_mod()
     c = CASES['mid']
