@@ -146,7 +146,7 @@ class VAEEngine:
         # tile and the latent kernel sums the partial slabs (slab 0 = self.mlv holds the complete values afterwards)
         heads_tiles = ((B + 63) // 64) * ((2 * D + 63) // 64)
         heads_kt = (self.flat_p * (2 if self.tdt != torch.float32 else 4) + 127) // 128
-        self.heads_splits = int(max(1, min(8, 256 // max(1, heads_tiles), heads_kt // 3))) \
+        self.heads_splits = int(max(1, min(int(os.environ.get('C1V_SPLITK_MAX', '8')), 256 // max(1, heads_tiles), heads_kt // 3))) \
             if os.environ.get('C1V_SPLITK', '1') == '1' else 1
         self.mlv_parts = z(self.heads_splits, B, 2 * D)
         self.mlv = self.mlv_parts[0]
