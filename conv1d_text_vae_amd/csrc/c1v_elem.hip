@@ -399,18 +399,27 @@ __global__ __launch_bounds__(256) void grad_finalize_kernel(const c1v_seg_desc* 
                 sq += (g[k].x * g[k].x + g[k].y * g[k].y) + (g[k].z * g[k].z + g[k].w * g[k].w);
             }
     } else {
+        // odd counts / unaligned slabs (the 302-wide output bias): one element per thread and pass, eight slabs requested
+        // per round with clamped, unconditional loads (an element-by-element loop over 18 splits was one serial round trip
+        // per slab and made this single block the longest of the launch); same (split, rep) summation order
+        for (int64_t i = base + threadIdx.x; i < base + C1V_CHUNK && i < d.count; i += 256) {
+            float g = 0.f;
+            if (!d.frozen) {
+                const int ns = d.splits * d.reps;
+                for (int s0 = 0; s0 < ns; s0 += 8) {
+                    float v[8];
 #pragma unroll
-        for (int k = 0; k < KI; ++k) {
-            const int64_t i = base + (int64_t)(k * 256 + threadIdx.x) * 4;
-            if (i >= d.count) continue;
-            for (int e = 0; e < 4 && i + e < d.count; ++e) {
-                float g = 0.f;
-                if (!d.frozen)
-                    for (int s = 0; s < d.splits; ++s)
-                        for (int r = 0; r < d.reps; ++r) g += d.slab[(int64_t)s * d.slab_stride + (int64_t)r * d.rep_stride + i + e];
-                grad[d.offset + i + e] = g;
-                sq += g * g;
+                    for (int q = 0; q < 8; ++q) {
+                        const int sq_ = s0 + q < ns ? s0 + q : ns - 1;
+                        const int sp = sq_ / d.reps, r = sq_ - sp * d.reps;
+                        v[q] = d.slab[(int64_t)sp * d.slab_stride + (int64_t)r * d.rep_stride + i];
+                    }
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) if (s0 + q < ns) g += v[q];
+                }
             }
+            grad[d.offset + i] = g;
+            sq += g * g;
         }
     }
     sq = block_sum_256(sq, red);

@@ -3,65 +3,42 @@
 #include "c1v_common.h"
 
 // loss scalars (single block, deterministic order)
-constexpr int LR_CAP = 8448;                       // row values staged per pass (256 samples of 32 steps at pitch 33)
 // (one workgroup of any whole number of waves <= 16; also run as an extra block of grad_finalize)
 __device__ __forceinline__ void loss_reduce_body(const float* __restrict__ xent_rows, const int* __restrict__ ids,
                                                  const float* __restrict__ kl_b, int B, int T_len, int B_global,
                                                  float* __restrict__ out3, float* __restrict__ xent_b) {
-    // Pass structure: all threads stage the per-step values of S = LR_CAP / (T + 1) samples in LDS with independent,
-    // coalesced loads (a wave-per-sample loop serialised one global-load latency per sample: 16 us at B = 256), then
-    // thread i sums the T steps of sample i in step order (pitch T + 1: conflict-free).  Every sum has a fixed order.
-    __shared__ float vx[LR_CAP];
-    __shared__ uint8_t vc[LR_CAP];
+    // Thread i owns sample i: it reads the T per-step values and ids of its row with independent 16-byte loads (all in
+    // flight together: one memory round trip per sample, no LDS staging, no barrier) and sums them in step order.  Every
+    // sum has a fixed order.
     __shared__ float sx[16], sk[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x, nwave = nthr >> 6;
     float ax = 0.f, ak = 0.f;
-    if (T_len <= LR_CAP / 2) {
-        const int pitch = T_len + 1, S = LR_CAP / pitch;
-        const float rcp = 1.0f / (float)T_len;
-        for (int base = 0; base < B; base += S) {
-            const int ns = B - base < S ? B - base : S, n = ns * T_len;
-            const float* xr = xent_rows + (int64_t)base * T_len;
-            const int* ir = ids + (int64_t)base * T_len;
-            const bool vec = (n & 3) == 0 && (((((uintptr_t)xr) | ((uintptr_t)ir)) & 15) == 0);
+    constexpr int LR_TMAX = 128;                   // longest row a single thread sums
+    if (T_len <= LR_TMAX) {
+        const bool vec = (T_len & 3) == 0 && (((((uintptr_t)xent_rows) | ((uintptr_t)ids)) & 15) == 0);
+        // samples go to the first 256 threads whatever the block size, so the order of every sum (and the result, bit for
+        // bit) is the same in the stand-alone kernel and as a block of grad_finalize
+        for (int b = tid; b < B && tid < 256; b += 256) {
+            const float kl = kl_b ? kl_b[b] : 0.f;
+            const float* xr = xent_rows + (int64_t)b * T_len;
+            const int* ir = ids + (int64_t)b * T_len;
+            float s = 0.f, c = 0.f;
             if (vec) {
-                // 16-byte words: four times fewer (independent) requests per thread
 #pragma unroll 8
-                for (int i4 = tid; i4 < (n >> 2); i4 += nthr) {
-                    const float4 xv = *(const float4*)(xr + 4 * i4);
-                    const int4 iv = *(const int4*)(ir + 4 * i4);
-                    const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
-                    const int is[4] = {iv.x, iv.y, iv.z, iv.w};
-                    int bl = (int)(((float)(4 * i4) + 0.5f) * rcp);
-                    int t = 4 * i4 - bl * T_len;
-                    if (t < 0) { --bl; t += T_len; } else if (t >= T_len) { ++bl; t -= T_len; }
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        vx[bl * pitch + t] = xs[k];
-                        vc[bl * pitch + t] = is[k] >= 0 ? 1 : 0;
-                        if (++t == T_len) { t = 0; ++bl; }
-                    }
+                for (int t = 0; t < T_len; t += 4) {
+                    const float4 xv = *(const float4*)(xr + t);
+                    const int4 iv = *(const int4*)(ir + t);
+                    s += xv.x; s += xv.y; s += xv.z; s += xv.w;
+                    c += (iv.x >= 0 ? 1.f : 0.f); c += (iv.y >= 0 ? 1.f : 0.f); c += (iv.z >= 0 ? 1.f : 0.f); c += (iv.w >= 0 ? 1.f : 0.f);
                 }
             } else {
-#pragma unroll 4
-                for (int i = tid; i < n; i += nthr) {
-                    int bl = (int)(((float)i + 0.5f) * rcp);
-                    int t = i - bl * T_len;
-                    if (t < 0) { --bl; t += T_len; } else if (t >= T_len) { ++bl; t -= T_len; }
-                    vx[bl * pitch + t] = xr[i];
-                    vc[bl * pitch + t] = ir[i] >= 0 ? 1 : 0;
-                }
+#pragma unroll 8
+                for (int t = 0; t < T_len; ++t) { s += xr[t]; c += ir[t] >= 0 ? 1.f : 0.f; }
             }
-            __syncthreads();
-            for (int bl = tid; bl < ns; bl += nthr) {
-                float s = 0.f, c = 0.f;
-                for (int t = 0; t < T_len; ++t) { s += vx[bl * pitch + t]; c += (float)vc[bl * pitch + t]; }
-                const float xb = s / c;
-                if (xent_b) xent_b[base + bl] = xb;
-                ax += xb;
-                ak += kl_b ? kl_b[base + bl] : 0.f;
-            }
-            __syncthreads();
+            const float xb = s / c;
+            if (xent_b) xent_b[b] = xb;
+            ax += xb;
+            ak += kl;
         }
         ax = wave_sum(ax); ak = wave_sum(ak);
     } else {
