@@ -666,12 +666,22 @@ class VAEEngine:
         # data-parallel buckets (reverse layer order): the decoder-side gradients are complete after the
         # first `n_dec_stages` backward stages and can be summed over the ranks while the rest of backward runs.  The
         # flat buffer keeps the segments in layer order, so each bucket is one contiguous range of `grads`.
-        is_enc = lambda n: n.startswith('encoder_conv1d_') or n.startswith('z_heads')
-        self.ops_finalize_dec = [make_finalize(seg_table(lambda n: not is_enc(n)), False, True)]
-        self.ops_finalize_enc = [make_finalize(seg_table(is_enc), False, False)]
-        self.n_dec_stages = nd + 2
-        self.enc_range = (0, self.seg_off['deconv_decoder_dense/kernel'])
-        self.dec_range = (self.seg_off['deconv_decoder_dense/kernel'], self.P)
+        # C2 with three buckets: decoder side (0.8 MB) after nd+2 stages, the latent heads (3.9 MB, the bulk of the model)
+        # after the next stage -- on the wire while the encoder convolutions' backward and its finalize run -- and the
+        # encoder convolutions (0.5 MB) at the end; C1V_DP_BUCKETS=2 keeps heads + encoder convolutions in one bucket.
+        is_conv = lambda n: n.startswith('encoder_conv1d_')
+        is_heads = lambda n: n.startswith('z_heads')
+        is_enc = lambda n: is_conv(n) or is_heads(n)
+        off_h, off_d = self.seg_off['z_heads/kernel'], self.seg_off['deconv_decoder_dense/kernel']
+        assert 0 < off_h < off_d < self.P and all((self.seg_off[n] < off_h) == is_conv(n) and
+                                                  (self.seg_off[n] >= off_d) == (not is_enc(n)) for n in self.seg_names)
+        # (bucket = backward stages [previous hi, hi), finalize launch over its segments, contiguous slice of `grads`)
+        self.dp_buckets = [(nd + 2, make_finalize(seg_table(lambda n: not is_enc(n)), False, True), (off_d, self.P))]
+        if os.environ.get('C1V_DP_BUCKETS', '3') == '3':
+            self.dp_buckets += [(nd + 3, make_finalize(seg_table(is_heads), False, False), (off_h, off_d)),
+                                (None, make_finalize(seg_table(is_conv), False, False), (0, off_h))]
+        else:
+            self.dp_buckets += [(None, make_finalize(seg_table(is_enc), False, False), (0, off_d))]
 
         def sqnorm():
             L.check(f_sq(self.grads.data_ptr(), self.P, self.sq_partial.data_ptr(), 256, self._stream()), 'c1v_sqnorm_partial')
@@ -861,10 +871,11 @@ class VAEEngine:
 
         world > 1 (data parallel, one process per GPU): `all_reduce(t)` sums a slice of the flat fp32 gradient over the
         ranks (RCCL over xGMI) and may return a work handle with `.wait()` (torch.distributed `async_op=True`).  The step
-        is three captured graphs around two bucketed collectives:
+        is one captured graph (or, if the collectives cannot be captured, one graph per bucket) over `dp_buckets`:
             A1 = forward + loss + decoder-side backward + finalize(decoder bucket)   -> all-reduce(decoder bucket) starts
-            A2 = encoder-side backward + finalize(encoder bucket)                    -> runs WHILE bucket 1 is on the wire
-            B  = |g|^2 of the reduced gradient, clip, Nadam, operand refresh         -> after both buckets
+            A2 = latent-heads backward + finalize(heads bucket)                      -> runs WHILE bucket 1 is on the wire
+            A3 = encoder-convolution backward + finalize(last bucket)                -> runs WHILE bucket 2 is on the wire
+            B  = |g|^2 of the reduced gradient, clip, Nadam, operand refresh         -> after all buckets
         Every loss term already carries 1/B_global, so the sum IS the full-batch gradient."""
         if self.N == 0:
             raise L.C1VError('train_step needs the vocabulary matrix (set_vocab)')
@@ -884,43 +895,48 @@ class VAEEngine:
             return
         if all_reduce is None:
             raise L.C1VError('world_size > 1 needs an all_reduce callable')
-        k = self.n_dec_stages
+        def bucket_ops(i):
+            """Backward stages and finalize launch of bucket i."""
+            lo = self.dp_buckets[i - 1][0] if i else 0
+            hi, fin, _ = self.dp_buckets[i]
+            return [lambda: self._run_backward(lo, hi), fin]
+
+        def reduce_bucket(i):
+            lo, hi = self.dp_buckets[i][2]
+            return all_reduce(self.grads[lo:hi])
+
+        nb = len(self.dp_buckets)
         if use_graph and os.environ.get('C1V_DP_GRAPH', '1') == '1' and not getattr(self, '_dp_graph_failed', False):
-            # the two collectives are captured INTO the step's graph (RCCL supports hipGraph capture): one launch per
-            # step, bucket 1 on the wire while the encoder-side backward runs.  Rehearsed here with one rank only
-            # (`bench.py --force-dp-path`), so a capture failure falls back to the three-graph sequence below.
+            # the collectives are captured INTO the step's graph (RCCL supports hipGraph capture): one launch per step,
+            # every bucket on the wire while the backward stages of the next one run.  Rehearsed here with one rank only
+            # (`bench.py --force-dp-path`), so a capture failure falls back to the graph-per-bucket sequence below.
             waits = []
-
-            def ar_dec():
-                waits.append(all_reduce(self.grads[self.dec_range[0]:self.dec_range[1]]))
-
-            def ar_enc():
-                waits.append(all_reduce(self.grads[self.enc_range[0]:self.enc_range[1]]))
 
             def join():
                 for w in waits:
                     if w is not None and hasattr(w, 'wait'):
                         w.wait()
                 del waits[:]
+            ops = self.forward_ops(not fixed_rng, from_ids, True)
+            for i in range(nb):
+                ops = ops + bucket_ops(i) + [lambda i=i: waits.append(reduce_bucket(i))]
             try:
-                go('train_dp1', self.forward_ops(not fixed_rng, from_ids, True) + [lambda: self._run_backward(0, k)] +
-                   self.ops_finalize_dec + [ar_dec, lambda: self._run_backward(k, None)] + self.ops_finalize_enc +
-                   [ar_enc, join] + self.update_ops())
+                go('train_dp1', ops + [join] + self.update_ops())
                 self._wop_stale = stale_after
                 return
             except Exception as exc:                                   # noqa: BLE001 - capture of a collective refused
                 import sys
-                print('c1dvae: capturing the RCCL collectives into the step graph failed (%s); using the three-graph '
-                      'sequence' % (exc,), file=sys.stderr)
+                print('c1dvae: capturing the RCCL collectives into the step graph failed (%s); using one graph per '
+                      'bucket' % (exc,), file=sys.stderr)
                 self._dp_graph_failed = True
                 self._graphs.pop('train_dp1' + ('_fixed' if fixed_rng else '') + sfx, None)
                 if getattr(self, '_saved_for_capture', None) is not None:
                     self._restore_state(self._saved_for_capture)
-        go('train_a1', self.forward_ops(not fixed_rng, from_ids, True) + [lambda: self._run_backward(0, k)] + self.ops_finalize_dec)
-        w1 = all_reduce(self.grads[self.dec_range[0]:self.dec_range[1]])
-        go('train_a2', [lambda: self._run_backward(k, None)] + self.ops_finalize_enc)
-        w2 = all_reduce(self.grads[self.enc_range[0]:self.enc_range[1]])
-        for w in (w1, w2):
+        works = []
+        for i in range(nb):
+            go('train_a%d' % (i + 1), (self.forward_ops(not fixed_rng, from_ids, True) if i == 0 else []) + bucket_ops(i))
+            works.append(reduce_bucket(i))
+        for w in works:
             if w is not None and hasattr(w, 'wait'):
                 w.wait()
         go('train_b', self.update_ops())

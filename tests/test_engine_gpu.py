@@ -322,29 +322,20 @@ def test_two_rank_bucketed_step_equals_single_rank_step():
         sl = slice(r * h, (r + 1) * h)
         load_fixed(e, x[sl], ids[sl], eps[sl], mask_e[sl], mask_d[sl])
         ranks.append(e)
-    assert ranks[0].dec_range[1] == ranks[0].P and ranks[0].enc_range[1] == ranks[0].dec_range[0]
+    bk = ranks[0].dp_buckets
+    assert len(bk) == 3 and bk[0][2][1] == ranks[0].P and bk[-1][2][0] == 0
+    assert all(bk[i][2][0] == bk[i + 1][2][1] for i in range(len(bk) - 1))          # contiguous slices, reverse layer order
     for step in range(3):
         full.train_step(use_graph=False, fixed_rng=True)
-        # the two "processes" interleaved at their collectives; the all-reduce is a sum of the two buckets
-        pending = []
-
-        def make_ar(r):
-            def ar(t):
-                pending.append((r, t))
-            return ar
-        k = ranks[0].n_dec_stages
-        for e in ranks:
-            e._run(e.forward_ops(False, advance=True) + [lambda e=e: e._run_backward(0, k)] + e.ops_finalize_dec)
-        lo, hi = ranks[0].dec_range
-        tot = ranks[0].grads[lo:hi] + ranks[1].grads[lo:hi]
-        for e in ranks:
-            e.grads[lo:hi].copy_(tot)
-        for e in ranks:
-            e._run([lambda e=e: e._run_backward(k, None)] + e.ops_finalize_enc)
-        lo, hi = ranks[0].enc_range
-        tot = ranks[0].grads[lo:hi] + ranks[1].grads[lo:hi]
-        for e in ranks:
-            e.grads[lo:hi].copy_(tot)
+        # the two "processes" interleaved at their collectives; the all-reduce is a sum of the two ranks' slices
+        for i, (hi_stage, _, (lo, hi)) in enumerate(bk):
+            lo_stage = bk[i - 1][0] if i else 0
+            for e in ranks:
+                e._run((e.forward_ops(False, advance=True) if i == 0 else []) +
+                       [lambda e=e: e._run_backward(lo_stage, hi_stage), e.dp_buckets[i][1]])
+            tot = ranks[0].grads[lo:hi] + ranks[1].grads[lo:hi]
+            for e in ranks:
+                e.grads[lo:hi].copy_(tot)
         for e in ranks:
             e._run(e.update_ops())
         torch.cuda.synchronize()
@@ -366,4 +357,4 @@ def test_two_rank_bucketed_step_equals_single_rank_step():
     for _ in range(2):
         e.train_step(use_graph=True, fixed_rng=True, all_reduce=fake_all_reduce)
     torch.cuda.synchronize()
-    assert calls[:2] == [e.dec_range[1] - e.dec_range[0], e.enc_range[1] - e.enc_range[0]] and np.isfinite(e.loss())
+    assert calls[:3] == [hi - lo for _, _, (lo, hi) in e.dp_buckets] and np.isfinite(e.loss())
