@@ -148,7 +148,7 @@ def main():
     ap.add_argument('--traffic', type=float, default=None,
                     help='HBM bytes per launch of the dominant kernel from a separate rocprofv3 --pmc pass (see profiles/)')
     ap.add_argument('--force-dp-path', action='store_true',
-                    help='rehearse the multi-rank step sequence (3 graphs + 2 bucketed RCCL all-reduces) at any world size')
+                    help='rehearse the multi-rank step sequence (bucketed RCCL all-reduces inside the step graph) at any world size')
     ap.add_argument('--kernel-only', action='store_true', help='only loop the dominant kernel (for rocprofv3 --pmc passes)')
     args = ap.parse_args()
     if args.traffic is None:
@@ -176,8 +176,14 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = 'cuda:%d' % local_rank
     dist = None
+    saved_stdout = None
     if world > 1 or args.force_dp_path:
         import torch.distributed as dist
+        # RCCL writes a version banner to the process's stdout when its communicator comes up; stdout must carry the one
+        # JSON line only, so file descriptor 1 points at stderr until that line is printed
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
         if args.force_dp_path and 'RANK' not in os.environ:
             os.environ.update(RANK='0', WORLD_SIZE='1', MASTER_ADDR='127.0.0.1', MASTER_PORT='29533')
         dist.init_process_group('nccl', device_id=torch.device(dev))
@@ -264,7 +270,10 @@ def main():
             out['predict'] = predict_leg(dev, args.dtype)
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()
-        print(json.dumps(out))
+        if saved_stdout is not None:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
+        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 
