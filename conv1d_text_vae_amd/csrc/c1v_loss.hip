@@ -13,6 +13,7 @@
 // ARGMAX (predict: fused per-row arg-max, lowest index wins ties).
 #include "c1v_common.h"
 #include <stdlib.h>
+#include <type_traits>
 #include "c1v_lossred.h"
 
 // ------------------------------------------------------------------------------------------------------
@@ -176,10 +177,12 @@ void vocab_stream_kernel(const bf16_raw* __restrict__ yhat, int M, const bf16_ra
 #pragma unroll
         for (int r = 0; r < 16; ++r) U[c][r] = 0.f;
     float sumexp[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) sumexp[mb] = 0.f;
     float best[MB];
     int best_idx[MB];
 #pragma unroll
-    for (int mb = 0; mb < MB; ++mb) { sumexp[mb] = 0.f; best[mb] = -3.0e38f; best_idx[mb] = 0x7fffffff; }
+    for (int mb = 0; mb < MB; ++mb) { best[mb] = -3.0e38f; best_idx[mb] = 0x7fffffff; }
 
     // Both requests and the yf loads (one-time cost).  The BUILTIN form on purpose: the compiler's own bookkeeping must
     // see that the yf loads are complete, or it keeps a `vmcnt(0)` in front of the first MFMA of EVERY tile (an asm wait
@@ -217,7 +220,66 @@ void vocab_stream_kernel(const bf16_raw* __restrict__ yhat, int M, const bf16_ra
 #pragma unroll
         for (int j = 0; j < G1; ++j) a1[0][j] = *(const uint4*)(smem + vs_off<CB>(l31, 2 * j + h));
     }
-    for (int t = t_begin; t < t_end; ++t) {
+    // GEMM1 accumulators.  In the GEMM1-only modes the VALU stage on block nb = 1 of tile t runs inside the nb = 0 MFMA
+    // batches of tile t+1 (block 1 is only cleared in front of its own batches), so no VALU work is left without MFMAs
+    // to hide behind; before the first tile block 1 holds values that never win / add nothing.
+    f32x16_t S[MB][2];
+    if constexpr (MODE != VS_ACCUM) {
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) S[mb][1][r] = -3.0e38f;
+    }
+    // VALU stage on accumulator regs [r0, r1) of block nb of the tile whose first vocabulary row is pn0 (tile index pt):
+    // exp2 (+ tail mask) / running sum / running arg-max.  tailc: the tile hangs over the end of the vocabulary.
+    auto post = [&](int nb, int r0, int r1, int pn0, int mb0, int mb1, auto tailc) {
+        constexpr bool TAIL = decltype(tailc)::value;
+#pragma unroll
+        for (int mb = mb0; mb < mb1; ++mb) {
+#if defined(VS_ABLATE) && (VS_ABLATE & 16)
+            if (S[mb][nb][r0] == 12345.f) best_idx[mb] = 1; else
+#endif
+            if constexpr (MODE == VS_ARGMAX) {
+                // Running arg-max per lane: the slice's maximum first (a few v_max), and only when it beats the running
+                // best of some lane -- ever rarer as the stream goes on -- the element-by-element search that also yields
+                // the row (in ascending row order with a strict compare: the lowest row wins ties).  Tracking the row of
+                // every logit cost ~8 VALU instructions each, as much issue time as the MFMAs of the tile.
+                float v[16];
+#pragma unroll
+                for (int r = r0; r < r1; ++r) {
+                    v[r] = S[mb][nb][r];
+                    if constexpr (TAIL) { const int n = pn0 + nb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h; if (n >= N) v[r] = -3.0e38f; }
+                }
+                float m = v[r0];
+#pragma unroll
+                for (int r = r0 + 1; r < r1; ++r) m = fmaxf(m, v[r]);
+                if (__builtin_amdgcn_ballot_w64(m > best[mb]) != 0) {
+#pragma unroll
+                    for (int r = r0; r < r1; ++r) {
+                        const int n = pn0 + nb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                        if (v[r] > best[mb]) { best[mb] = v[r]; best_idx[mb] = n; }
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int r = r0; r < r1; ++r) {
+#if defined(VS_ABLATE) && (VS_ABLATE & 1)
+                    float e = S[mb][nb][r];
+#else
+                    float e = __builtin_amdgcn_exp2f(S[mb][nb][r]);
+#endif
+                    if constexpr (MODE == VS_SUMEXP) {
+                        // (ACCUM needs no tail mask: rows >= N of W are all-zero, ones column included, so whatever
+                        // exp2 gives for them is multiplied by zero in GEMM2)
+                        if constexpr (TAIL) { const int n = pn0 + nb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h; if (n >= N) e = 0.f; }
+                        sumexp[mb] += e;
+                    }
+                    S[mb][nb][r] = e;
+                }
+            }
+        }
+    };
+    auto tile_body = [&](int t, auto tailc) {
         VS_T(7);
         const int stage = (t - t_begin) % VS_STAGES;
 #if defined(VS_ABLATE) && (VS_ABLATE & 8)
@@ -227,9 +289,12 @@ void vocab_stream_kernel(const bf16_raw* __restrict__ yhat, int M, const bf16_ra
         const char* sw = smem + stage * Cfg::STAGE;
 #endif
         const int n0 = t * VS_BN;
-        const bool tail = n0 + VS_BN > N;
 
+#if defined(VS_ABLATE) && (VS_ABLATE & 32)
+        auto ld1 = [&](int nb, int s) -> uint4 { return make_uint4(l31 + nb, h + s, t, 0x3f803f80u); };
+#else
         auto ld1 = [&](int nb, int s) -> uint4 { return *(const uint4*)(sw + vs_off<CB>(nb * 32 + l31, 2 * s + h)); };
+#endif
         // W^T fragment of GEMM2: k slot (h, j) of step (nb, ks) is vocabulary row nb*32 + 16ks + 8(j>>2) + 4h + (j&3),
         // exactly the accumulator rows held in regs 8ks..8ks+7 of S[nb]
         auto ld2 = [&](int nb, int ks, int cb) -> uint4 {
@@ -242,45 +307,26 @@ void vocab_stream_kernel(const bf16_raw* __restrict__ yhat, int M, const bf16_ra
                               __builtin_bit_cast(uint2, hi).x, __builtin_bit_cast(uint2, hi).y);
         };
 
-        f32x16_t S[MB][2];
+        // (block 1 of the GEMM1-only modes still holds the previous tile's logits: cleared in front of its own batches)
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-            for (int nb = 0; nb < 2; ++nb)
+            for (int nb = 0; nb < (MODE == VS_ACCUM ? 2 : 1); ++nb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) S[mb][nb][r] = 0.f;
-
-        // VALU stage on accumulator regs [r0, r1) of block nb: exp2 (+ tail mask) / running sum / running arg-max
-        auto post = [&](int nb, int r0, int r1) {
-#pragma unroll
-            for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-            for (int r = r0; r < r1; ++r) {
-                if constexpr (MODE == VS_ARGMAX) {
-                    const int n = n0 + nb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    const float v = S[mb][nb][r];
-                    if (n < N && v > best[mb]) { best[mb] = v; best_idx[mb] = n; }
-                } else {
-#if defined(VS_ABLATE) && (VS_ABLATE & 1)
-                    float e = S[mb][nb][r];
-#else
-                    float e = __builtin_amdgcn_exp2f(S[mb][nb][r]);
-#endif
-                    if constexpr (MODE == VS_SUMEXP) {
-                        // (ACCUM needs no tail mask: rows >= N of W are all-zero, ones column included, so whatever
-                        // exp2 gives for them is multiplied by zero in GEMM2)
-                        if (tail) { const int n = n0 + nb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h; if (n >= N) e = 0.f; }
-                        sumexp[mb] += e;
-                    }
-                    S[mb][nb][r] = e;
-                }
-            }
-        };
 
         uint4 a2[3][CG * 2];
 #pragma unroll
         for (int q = 0; q < Q1; ++q) {
             const int nb = q / NB1, s0 = (q % NB1) * G1;
+            if constexpr (MODE != VS_ACCUM) {
+                if (q == NB1) {
+#pragma unroll
+                    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) S[mb][1][r] = 0.f;
+                }
+            }
             if (q + 1 < Q1) {
                 const int nb2 = (q + 1) / NB1, s2 = ((q + 1) % NB1) * G1;
 #pragma unroll
@@ -304,6 +350,17 @@ void vocab_stream_kernel(const bf16_raw* __restrict__ yhat, int M, const bf16_ra
                     for (int mb = 0; mb < MB; ++mb)
                         S[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a1[q & 1][j]), yf[mb][s0 + j], S[mb][nb], 0, 0, 0);
                 }
+                if constexpr (MODE == VS_ARGMAX) {
+                    // the arg-max stage of one m-block (a handful of VALU instructions and a rarely taken branch) sits behind
+                    // the j-th MFMAs in program order: it issues while they run.  nb = 0 batches take block 1 of the PREVIOUS
+                    // tile (never a tail tile: the tail is the last one), nb = 1 batches block 0 of this tile.
+                    if (j < MB) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (nb == 0) post(1, q * 16 / NB1, (q + 1) * 16 / NB1, n0 - VS_BN, j, j + 1, std::false_type{});
+                        else post(0, (q - NB1) * 16 / NB1, (q - NB1 + 1) * 16 / NB1, n0, j, j + 1, tailc);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
             }
 #if !(defined(VS_ABLATE) && (VS_ABLATE & 8))
             if constexpr (MODE != VS_ACCUM) {
@@ -326,15 +383,26 @@ void vocab_stream_kernel(const bf16_raw* __restrict__ yhat, int M, const bf16_ra
                 }
             }
 #endif
-            if (nb == 1) post(0, (q - NB1) * 16 / NB1, (q - NB1 + 1) * 16 / NB1);
+            if constexpr (MODE == VS_ACCUM) {
+                if (nb == 1) post(0, (q - NB1) * 16 / NB1, (q - NB1 + 1) * 16 / NB1, n0, 0, MB, std::false_type{});
+            } else if constexpr (MODE == VS_SUMEXP) {
+                // exp2 + running sum: block 1 of the previous tile (never a tail tile) behind the nb = 0 batches, block 0 of
+                // this tile behind the nb = 1 batches; one MFMA, then its share of the VALU stage
+                if (nb == 0) post(1, q * 16 / NB1, (q + 1) * 16 / NB1, n0 - VS_BN, 0, MB, std::false_type{});
+                else post(0, (q - NB1) * 16 / NB1, (q - NB1 + 1) * 16 / NB1, n0, 0, MB, tailc);
+                constexpr int VPM = (16 * 2 + KS - 1) / KS + 1;
+#pragma unroll
+                for (int i = 0; i < G1 * MB; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);
+                }
+            }
             __builtin_amdgcn_sched_barrier(0);
             if (q == NB1 - 1) VS_T(0);
             if (q == Q1 - 1) VS_T(1);
         }
 
-        if constexpr (MODE != VS_ACCUM) {
-            post(1, 0, 16);
-        } else {
+        if constexpr (MODE == VS_ACCUM) {
             bf16x8_t pf[2][2];
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
@@ -386,11 +454,23 @@ void vocab_stream_kernel(const bf16_raw* __restrict__ yhat, int M, const bf16_ra
                     for (int j = 0; j < G1; ++j) a1[0][j] = *(const uint4*)(swn + vs_off<CB>(l31, 2 * j + h));
                 }
 #endif
-                if (nb == 0) post(1, q * 16 / NB2, (q + 1) * 16 / NB2);
+                if (nb == 0) post(1, q * 16 / NB2, (q + 1) * 16 / NB2, n0, 0, MB, std::false_type{});
                 __builtin_amdgcn_sched_barrier(0);
                 if (q == NB2 - 1) VS_T(2);
                 if (q == Q2 - 1) VS_T(3);
             }
+        }
+    };
+    for (int t = t_begin; t < t_end; ++t) {
+        if (MODE != VS_ACCUM && t * VS_BN + VS_BN > N) tile_body(t, std::true_type{});
+        else tile_body(t, std::false_type{});
+    }
+    if constexpr (MODE != VS_ACCUM) {
+        // block 1 of the last tile
+        if (t_begin < t_end) {
+            const int tl = t_end - 1;
+            if (tl * VS_BN + VS_BN > N) post(1, 0, 16, tl * VS_BN, 0, MB, std::true_type{});
+            else post(1, 0, 16, tl * VS_BN, 0, MB, std::false_type{});
         }
     }
 #ifdef VS_STAMP
