@@ -197,8 +197,13 @@ void vocab_stream_kernel(const bf16_raw* __restrict__ yhat, int M, const bf16_ra
     //   GEMM1 nb=0 | GEMM1 nb=1 + exp2(S0) | GEMM2 nb=0 + exp2(S1) | GEMM2 nb=1
     // sched_barrier(0) pins "loads of batch q+1, then MFMAs of batch q" (the compiler otherwise re-serialises every
     // ds_read behind an lgkmcnt(0) in front of its MFMA, which tripled the tile time).
-    constexpr int G1 = (KS % 5 == 0) ? 5 : KS;          // GEMM1 fragments per batch
-    constexpr int NB1 = KS / G1, Q1 = 2 * NB1;
+    // GEMM1 batch: KB k-steps of BOTH 32-row blocks of the tile, issued alternately -- consecutive MFMAs never accumulate
+    // into the same registers.  Measured on gfx950 (scratch micro-benchmark): a chain of dependent 32x32x16 MFMAs runs at
+    // 55 cycles each, two or more independent chains at 37; and VALU instructions issued between MFMAs do NOT hide behind
+    // them (each costs ~3 cycles of MFMA throughput), so the VALU stages simply follow GEMM1.
+    constexpr int KB = 2, G1 = 2 * KB;                  // k-steps / fragments per batch
+    constexpr int Q1 = KS / KB, HB = (Q1 + 1) / 2;      // batches; the GEMM1-only modes put their barrier behind batch HB-1
+    static_assert(KS % KB == 0, "k-steps come in pairs");
     constexpr int CG = (CB % 2 == 0) ? 2 : 1;           // GEMM2: cb blocks per batch (2 k-steps each)
     constexpr int NB2 = CB / CG, Q2 = 2 * NB2;
     const int tq = (lane & 15) >> 2, tpq = lane & 3, tcg = (lane >> 4) & 1;
@@ -218,18 +223,9 @@ void vocab_stream_kernel(const bf16_raw* __restrict__ yhat, int M, const bf16_ra
     uint4 a1[2][G1];
     if (t_begin < t_end) {
 #pragma unroll
-        for (int j = 0; j < G1; ++j) a1[0][j] = *(const uint4*)(smem + vs_off<CB>(l31, 2 * j + h));
+        for (int f = 0; f < G1; ++f) a1[0][f] = *(const uint4*)(smem + vs_off<CB>((f & 1) * 32 + l31, 2 * (f >> 1) + h));
     }
-    // GEMM1 accumulators.  In the GEMM1-only modes the VALU stage on block nb = 1 of tile t runs inside the nb = 0 MFMA
-    // batches of tile t+1 (block 1 is only cleared in front of its own batches), so no VALU work is left without MFMAs
-    // to hide behind; before the first tile block 1 holds values that never win / add nothing.
-    f32x16_t S[MB][2];
-    if constexpr (MODE != VS_ACCUM) {
-#pragma unroll
-        for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) S[mb][1][r] = -3.0e38f;
-    }
+    f32x16_t S[MB][2];                             // GEMM1 accumulators: the two 32-row blocks of the vocabulary tile
     // VALU stage on accumulator regs [r0, r1) of block nb of the tile whose first vocabulary row is pn0 (tile index pt):
     // exp2 (+ tail mask) / running sum / running arg-max.  tailc: the tile hangs over the end of the vocabulary.
     auto post = [&](int nb, int r0, int r1, int pn0, int mb0, int mb1, auto tailc) {
@@ -307,30 +303,20 @@ void vocab_stream_kernel(const bf16_raw* __restrict__ yhat, int M, const bf16_ra
                               __builtin_bit_cast(uint2, hi).x, __builtin_bit_cast(uint2, hi).y);
         };
 
-        // (block 1 of the GEMM1-only modes still holds the previous tile's logits: cleared in front of its own batches)
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-            for (int nb = 0; nb < (MODE == VS_ACCUM ? 2 : 1); ++nb)
+            for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) S[mb][nb][r] = 0.f;
 
         uint4 a2[3][CG * 2];
 #pragma unroll
         for (int q = 0; q < Q1; ++q) {
-            const int nb = q / NB1, s0 = (q % NB1) * G1;
-            if constexpr (MODE != VS_ACCUM) {
-                if (q == NB1) {
-#pragma unroll
-                    for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) S[mb][1][r] = 0.f;
-                }
-            }
+            const int s0 = q * KB;
             if (q + 1 < Q1) {
-                const int nb2 = (q + 1) / NB1, s2 = ((q + 1) % NB1) * G1;
 #pragma unroll
-                for (int j = 0; j < G1; ++j) a1[(q + 1) & 1][j] = ld1(nb2, s2 + j);
+                for (int f = 0; f < G1; ++f) a1[(q + 1) & 1][f] = ld1(f & 1, s0 + KB + (f >> 1));
             } else if constexpr (MODE == VS_ACCUM) {
 #pragma unroll
                 for (int qq = 0; qq < 2 && qq < Q2; ++qq)
@@ -341,73 +327,55 @@ void vocab_stream_kernel(const bf16_raw* __restrict__ yhat, int M, const bf16_ra
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int j = 0; j < G1; ++j) {
+            for (int f = 0; f < G1; ++f) {
 #if defined(VS_ABLATE) && (VS_ABLATE & 4)
-                if (j == 0 && s0 == 0)
+                if (f == 0 && s0 == 0)
 #endif
                 {
 #pragma unroll
                     for (int mb = 0; mb < MB; ++mb)
-                        S[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a1[q & 1][j]), yf[mb][s0 + j], S[mb][nb], 0, 0, 0);
-                }
-                if constexpr (MODE == VS_ARGMAX) {
-                    // the arg-max stage of one m-block (a handful of VALU instructions and a rarely taken branch) sits behind
-                    // the j-th MFMAs in program order: it issues while they run.  nb = 0 batches take block 1 of the PREVIOUS
-                    // tile (never a tail tile: the tail is the last one), nb = 1 batches block 0 of this tile.
-                    if (j < MB) {
-                        __builtin_amdgcn_sched_barrier(0);
-                        if (nb == 0) post(1, q * 16 / NB1, (q + 1) * 16 / NB1, n0 - VS_BN, j, j + 1, std::false_type{});
-                        else post(0, (q - NB1) * 16 / NB1, (q - NB1 + 1) * 16 / NB1, n0, j, j + 1, tailc);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
+                        S[mb][f & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a1[q & 1][f]), yf[mb][s0 + (f >> 1)],
+                                                                               S[mb][f & 1], 0, 0, 0);
                 }
             }
 #if !(defined(VS_ABLATE) && (VS_ABLATE & 8))
             if constexpr (MODE != VS_ACCUM) {
-                // GEMM1-only modes: barrier behind the nb = 0 half, request for tile t+2 behind the nb = 1 batches (one
-                // wave per batch where there are enough batches), first fragments of tile t+1 behind the last batch
-                if (q == NB1 - 1) {
+                // GEMM1-only modes: the tile's barrier sits behind batch HB-1, the request for tile t+2 behind a later batch
+                // (a different one per wave where there are enough), the first fragments of tile t+1 behind the last batch
+                if (q == HB - 1) {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     VS_T(4);
                     __syncthreads();
                     VS_T(5);
                 }
-                if ((NB1 >= 4 ? q == NB1 + wave : q == NB1) && more) {
+                constexpr int QD = HB < Q1 ? HB : Q1 - 1;                  // first batch behind the barrier (Q1 == 1: the batch itself)
+                if ((Q1 - QD >= 4 ? q == QD + wave : q == QD) && more) {
 #pragma unroll
                     for (int i = 0; i < Cfg::PPW; ++i) stage_piece(t + 2, (stage + 2) % VS_STAGES, i);
                 }
                 if (q == Q1 - 1 && t + 1 < t_end) {
                     const char* swn1 = smem + ((t + 1 - t_begin) % VS_STAGES) * Cfg::STAGE;
 #pragma unroll
-                    for (int j = 0; j < G1; ++j) a1[0][j] = *(const uint4*)(swn1 + vs_off<CB>(l31, 2 * j + h));
+                    for (int f = 0; f < G1; ++f) a1[0][f] = *(const uint4*)(swn1 + vs_off<CB>((f & 1) * 32 + l31, 2 * (f >> 1) + h));
                 }
             }
 #endif
-            if constexpr (MODE == VS_ACCUM) {
-                if (nb == 1) post(0, (q - NB1) * 16 / NB1, (q - NB1 + 1) * 16 / NB1, n0, 0, MB, std::false_type{});
-            } else if constexpr (MODE == VS_SUMEXP) {
-                // exp2 + running sum: block 1 of the previous tile (never a tail tile) behind the nb = 0 batches, block 0 of
-                // this tile behind the nb = 1 batches; one MFMA, then its share of the VALU stage
-                if (nb == 0) post(1, q * 16 / NB1, (q + 1) * 16 / NB1, n0 - VS_BN, 0, MB, std::false_type{});
-                else post(0, (q - NB1) * 16 / NB1, (q - NB1 + 1) * 16 / NB1, n0, 0, MB, tailc);
-                constexpr int VPM = (16 * 2 + KS - 1) / KS + 1;
-#pragma unroll
-                for (int i = 0; i < G1 * MB; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);
-                }
-            }
             __builtin_amdgcn_sched_barrier(0);
-            if (q == NB1 - 1) VS_T(0);
+            if (q == HB - 1) VS_T(0);
             if (q == Q1 - 1) VS_T(1);
         }
+        // VALU stage on both blocks
+        post(0, 0, 16, n0, 0, MB, tailc);
+        post(1, 0, 16, n0, 0, MB, tailc);
 
         if constexpr (MODE == VS_ACCUM) {
             bf16x8_t pf[2][2];
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
+            for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) pf[0][ks][j] = (__bf16)S[0][0][8 * ks + j];
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) pf[nb][ks][j] = (__bf16)S[0][nb][8 * ks + j];
 #if !(defined(VS_ABLATE) && (VS_ABLATE & 8))
             // the tile's only barrier: tile t+1 (this wave's pieces: everything it has in flight) is in LDS, tile t-1 is dead
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -426,17 +394,12 @@ void vocab_stream_kernel(const bf16_raw* __restrict__ yhat, int M, const bf16_ra
 #pragma unroll
                         for (int ks = 0; ks < 2; ++ks) a2[(q + 2) % 3][c * 2 + ks] = ld2(nb2, ks, cb2 + c);
                 }
-                if (q == NB2) {
-#pragma unroll
-                    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) pf[1][ks][j] = (__bf16)S[0][1][8 * ks + j];
-                }
                 __builtin_amdgcn_sched_barrier(0);
+                // (k-step outside, column block inside: consecutive MFMAs accumulate into different registers)
 #pragma unroll
-                for (int c = 0; c < CG; ++c)
+                for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-                    for (int ks = 0; ks < 2; ++ks)
+                    for (int c = 0; c < CG; ++c)
 #if defined(VS_ABLATE) && (VS_ABLATE & 2)
                         if (cb0 + c == 0)
 #endif
@@ -451,10 +414,9 @@ void vocab_stream_kernel(const bf16_raw* __restrict__ yhat, int M, const bf16_ra
                 // first GEMM1 fragments of tile t+1, behind the last batch
                 if (q == Q2 - 1 && t + 1 < t_end) {
 #pragma unroll
-                    for (int j = 0; j < G1; ++j) a1[0][j] = *(const uint4*)(swn + vs_off<CB>(l31, 2 * j + h));
+                    for (int f = 0; f < G1; ++f) a1[0][f] = *(const uint4*)(swn + vs_off<CB>((f & 1) * 32 + l31, 2 * (f >> 1) + h));
                 }
 #endif
-                if (nb == 0) post(1, q * 16 / NB2, (q + 1) * 16 / NB2, n0, 0, MB, std::false_type{});
                 __builtin_amdgcn_sched_barrier(0);
                 if (q == NB2 - 1) VS_T(2);
                 if (q == Q2 - 1) VS_T(3);
@@ -464,14 +426,6 @@ void vocab_stream_kernel(const bf16_raw* __restrict__ yhat, int M, const bf16_ra
     for (int t = t_begin; t < t_end; ++t) {
         if (MODE != VS_ACCUM && t * VS_BN + VS_BN > N) tile_body(t, std::true_type{});
         else tile_body(t, std::false_type{});
-    }
-    if constexpr (MODE != VS_ACCUM) {
-        // block 1 of the last tile
-        if (t_begin < t_end) {
-            const int tl = t_end - 1;
-            if (tl * VS_BN + VS_BN > N) post(1, 0, 16, tl * VS_BN, 0, MB, std::true_type{});
-            else post(1, 0, 16, tl * VS_BN, 0, MB, std::false_type{});
-        }
     }
 #ifdef VS_STAMP
     unsigned long long tloop;
