@@ -191,12 +191,10 @@ void vocab_stream_kernel(const bf16_raw* __restrict__ yhat, int M, const bf16_ra
     asm volatile("" ::: "memory");
     __syncthreads();
 
-    // Software pipeline of one tile (one wave per SIMD, so nothing else hides LDS latency): operand fragments are
-    // fetched one BATCH ahead into a second register buffer, and the VALU work on a finished accumulator block is
-    // issued inside the MFMA groups of the next block:
-    //   GEMM1 nb=0 | GEMM1 nb=1 + exp2(S0) | GEMM2 nb=0 + exp2(S1) | GEMM2 nb=1
-    // sched_barrier(0) pins "loads of batch q+1, then MFMAs of batch q" (the compiler otherwise re-serialises every
-    // ds_read behind an lgkmcnt(0) in front of its MFMA, which tripled the tile time).
+    // Software pipeline of one tile (one wave per SIMD, so nothing else hides LDS latency): operand fragments are fetched
+    // one BATCH ahead into a second register buffer.  sched_barrier(0) pins "loads of batch q+1, then MFMAs of batch q"
+    // (the compiler otherwise re-serialises every ds_read behind an lgkmcnt(0) in front of its MFMA, which tripled the
+    // tile time).
     // GEMM1 batch: KB k-steps of BOTH 32-row blocks of the tile, issued alternately -- consecutive MFMAs never accumulate
     // into the same registers.  Measured on gfx950 (scratch micro-benchmark): a chain of dependent 32x32x16 MFMAs runs at
     // 55 cycles each, two or more independent chains at 37; and VALU instructions issued between MFMAs do NOT hide behind
@@ -213,13 +211,15 @@ void vocab_stream_kernel(const bf16_raw* __restrict__ yhat, int M, const bf16_ra
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev) :: "memory");
     const unsigned long long tstart = tprev;
 #endif
-    // ACCUM mode runs a tile as  GEMM1(t) | wait + barrier | GEMM2(t)  with ONE barrier, in the middle of the tile:
+    // ACCUM mode runs a tile as  GEMM1(t) | exp2, bf16 | wait + barrier | GEMM2(t)  with ONE barrier, in the middle of the tile:
     //   * it publishes tile t+1 (requested during GEMM2 of tile t-1) and proves that every wave is done with tile t-1, whose
     //     stage the request for tile t+2 -- sent right after it, behind the GEMM2 batches -- overwrites;
     //   * nothing separates the end of GEMM2(t) from GEMM1(t+1), so the first fragments of tile t+1 are fetched behind the
-    //     last GEMM2 batch of tile t (with the barrier at the end of the tile every tile began with an exposed LDS round
-    //     trip and a barrier skew: GEMM1's first half took 1450 cycles against 900 for the second, exp2 work included).
-    // The other modes (no GEMM2) put the same single barrier between the two halves (nb = 0 | nb = 1) of GEMM1.
+    //     last GEMM2 batch of tile t.
+    // The other modes (no GEMM2) put the same single barrier in the middle of GEMM1.  In-kernel stamps (VS_STAMP build) of
+    // the ACCUM form at C2: GEMM1 and the second half of GEMM2 run at the MFMA rate (~37 cycles each); the LDS-DMA requests
+    // and their LDS writes cost ~20 % of the tile, the exp2 / bf16 stage ~8 %.  A form with wave PAIRS (each LDS fragment
+    // feeding two MFMAs, half the LDS reads) was built and measured: no faster, so LDS read bandwidth is not the limit.
     uint4 a1[2][G1];
     if (t_begin < t_end) {
 #pragma unroll
@@ -438,6 +438,7 @@ void vocab_stream_kernel(const bf16_raw* __restrict__ yhat, int M, const bf16_ra
         // this wave's private 4.5 KB of LDS (the W stages are dead after the loop's last barrier) and store 128-byte
         // row segments: UT[split][m][c].
         constexpr int TP = 36;                                  // floats per transposed row (32 + 4 pad)
+        __syncthreads();                                        // (slower waves may still be reading the last tile)
         float* tw = (float*)smem + wave * 32 * TP;
         float* o = ut + ((int64_t)split * m_pad + bx * VS_BM + wave * 32) * Cfg::KP;
 #pragma unroll
