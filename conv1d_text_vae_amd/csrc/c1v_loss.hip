@@ -116,6 +116,10 @@ void vocab_stream_kernel(const bf16_raw* __restrict__ yhat, int M, const bf16_ra
     static_assert(MB == 1 || MODE != VS_ACCUM, "ACCUM has no registers for a second m-block");
     constexpr int WG_ROWS = VS_BM * MB;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef VS_STAMP
+    unsigned long long t_entry;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_entry) :: "memory");
+#endif
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, h = lane >> 5;
@@ -218,7 +222,8 @@ void vocab_stream_kernel(const bf16_raw* __restrict__ yhat, int M, const bf16_ra
     //     last GEMM2 batch of tile t.
     // The other modes (no GEMM2) put the same single barrier in the middle of GEMM1.  In-kernel stamps (VS_STAMP build) of
     // the ACCUM form at C2: GEMM1 and the second half of GEMM2 run at the MFMA rate (~37 cycles each); the LDS-DMA requests
-    // and their LDS writes cost ~20 % of the tile, the exp2 / bf16 stage ~8 %.  A form with wave PAIRS (each LDS fragment
+    // and their LDS writes cost ~20 % of the tile, the exp2 / bf16 stage ~8 %; the prologue (first two tiles and the Yhat
+    // fragments, every workgroup at once) is ~10 % of the kernel, the U write-out ~4 %.  A form with wave PAIRS (each LDS fragment
     // feeding two MFMAs, half the LDS reads) was built and measured: no faster, so LDS read bandwidth is not the limit.
     uint4 a1[2][G1];
     if (t_begin < t_end) {
@@ -480,6 +485,8 @@ void vocab_stream_kernel(const bf16_raw* __restrict__ yhat, int M, const bf16_ra
         const int wg = blockIdx.x + gridDim.x * blockIdx.y;
         if (wg < 4096) {
             for (int i = 0; i < 6; ++i) vs_dbg[wg * 8 + i] = seg[i];
+            // (slot 5 carries the prologue -- entry to first tile -- times the tile count: the reader divides per tile)
+            vs_dbg[wg * 8 + 5] = (tstart - t_entry) * (unsigned long long)(t_end - t_begin);
             vs_dbg[wg * 8 + 6] = tloop - tstart;
             vs_dbg[wg * 8 + 7] = tend - tloop;
         }
