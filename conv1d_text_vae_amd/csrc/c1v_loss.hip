@@ -308,13 +308,10 @@ void vocab_stream_kernel(const bf16_raw* __restrict__ yhat, int M, const bf16_ra
                               __builtin_bit_cast(uint2, hi).x, __builtin_bit_cast(uint2, hi).y);
         };
 
+        // (no clearing of S: the first MFMA of every accumulator chain takes a constant-zero C operand)
+        f32x16_t zero16;
 #pragma unroll
-        for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-            for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) S[mb][nb][r] = 0.f;
-
+        for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
         uint4 a2[3][CG * 2];
 #pragma unroll
         for (int q = 0; q < Q1; ++q) {
@@ -340,7 +337,7 @@ void vocab_stream_kernel(const bf16_raw* __restrict__ yhat, int M, const bf16_ra
 #pragma unroll
                     for (int mb = 0; mb < MB; ++mb)
                         S[mb][f & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a1[q & 1][f]), yf[mb][s0 + (f >> 1)],
-                                                                               S[mb][f & 1], 0, 0, 0);
+                                                                               (q == 0 && f < 2) ? zero16 : S[mb][f & 1], 0, 0, 0);
                 }
             }
 #if !(defined(VS_ABLATE) && (VS_ABLATE & 8))
