@@ -225,10 +225,25 @@ void vocab_stream_kernel(const bf16_raw* __restrict__ yhat, int M, const bf16_ra
     // and their LDS writes cost ~20 % of the tile, the exp2 / bf16 stage ~8 %; the prologue (first two tiles and the Yhat
     // fragments, every workgroup at once) is ~10 % of the kernel, the U write-out ~4 %.  A form with wave PAIRS (each LDS fragment
     // feeding two MFMAs, half the LDS reads) was built and measured: no faster, so LDS read bandwidth is not the limit.
+    // LDS addresses of the fragment reads = (stage base + a lane constant) + a COMPILE-TIME offset, so that every ds_read
+    // carries its offset as an immediate and a tile needs four address additions in all (the swizzle only touches the low
+    // two chunk bits and depends on the row through (row >> 2) & 3, which the +32 / +16 row steps of the fragments leave
+    // alone; written with vs_off() per read, the compiler spent ~130 VALU instructions per tile on addresses, and VALU
+    // instructions are not free next to MFMAs):
+    //   GEMM1 fragment (nb, s):      vs_off(nb*32 + l31, 2s + h)        = g1off[s & 1] + nb*32*PITCH + (s >> 1)*64
+    //   GEMM2 fragment (nb, ks, cb): vs_off(nb*32 + 16ks + R [+8], 4cb + c0) + sub = g2off[lo|hi] + (nb*32 + 16ks)*PITCH + cb*64
+    int g1off[2];
+#pragma unroll
+    for (int par = 0; par < 2; ++par) g1off[par] = vs_off<CB>(l31, 2 * par + h);
+    const int g2off_lo = vs_off<CB>(4 * h + tq, 2 * tcg + (tpq >> 1)) + 8 * (tpq & 1);
+    const int g2off_hi = vs_off<CB>(4 * h + tq + 8, 2 * tcg + (tpq >> 1)) + 8 * (tpq & 1);
+    auto ld1_at = [&](const char* base, int nb, int s) -> uint4 {
+        return *(const uint4*)(base + g1off[s & 1] + nb * 32 * Cfg::PITCH + (s >> 1) * 64);
+    };
     uint4 a1[2][G1];
     if (t_begin < t_end) {
 #pragma unroll
-        for (int f = 0; f < G1; ++f) a1[0][f] = *(const uint4*)(smem + vs_off<CB>((f & 1) * 32 + l31, 2 * (f >> 1) + h));
+        for (int f = 0; f < G1; ++f) a1[0][f] = ld1_at(smem, f & 1, f >> 1);
     }
     f32x16_t S[MB][2];                             // GEMM1 accumulators: the two 32-row blocks of the vocabulary tile
     // VALU stage on accumulator regs [r0, r1) of block nb of the tile whose first vocabulary row is pn0 (tile index pt):
@@ -237,9 +252,6 @@ void vocab_stream_kernel(const bf16_raw* __restrict__ yhat, int M, const bf16_ra
         constexpr bool TAIL = decltype(tailc)::value;
 #pragma unroll
         for (int mb = mb0; mb < mb1; ++mb) {
-#if defined(VS_ABLATE) && (VS_ABLATE & 16)
-            if (S[mb][nb][r0] == 12345.f) best_idx[mb] = 1; else
-#endif
             if constexpr (MODE == VS_ARGMAX) {
                 // Running arg-max per lane: the slice's maximum first (a few v_max), and only when it beats the running
                 // best of some lane -- ever rarer as the stream goes on -- the element-by-element search that also yields
@@ -291,19 +303,13 @@ void vocab_stream_kernel(const bf16_raw* __restrict__ yhat, int M, const bf16_ra
 #endif
         const int n0 = t * VS_BN;
 
-#if defined(VS_ABLATE) && (VS_ABLATE & 32)
-        auto ld1 = [&](int nb, int s) -> uint4 { return make_uint4(l31 + nb, h + s, t, 0x3f803f80u); };
-#else
-        auto ld1 = [&](int nb, int s) -> uint4 { return *(const uint4*)(sw + vs_off<CB>(nb * 32 + l31, 2 * s + h)); };
-#endif
+        auto ld1 = [&](int nb, int s) -> uint4 { return ld1_at(sw, nb, s); };
         // W^T fragment of GEMM2: k slot (h, j) of step (nb, ks) is vocabulary row nb*32 + 16ks + 8(j>>2) + 4h + (j&3),
         // exactly the accumulator rows held in regs 8ks..8ks+7 of S[nb]
         auto ld2 = [&](int nb, int ks, int cb) -> uint4 {
-            const int chunk = cb * 4 + 2 * tcg + (tpq >> 1);
-            const int sub = 8 * (tpq & 1);
-            const int r0 = nb * 32 + 16 * ks + 4 * h + tq;
-            s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(C1V_LDS_PTR(s16x4_t, sw + vs_off<CB>(r0, chunk) + sub));
-            s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(C1V_LDS_PTR(s16x4_t, sw + vs_off<CB>(r0 + 8, chunk) + sub));
+            const int imm = (nb * 32 + 16 * ks) * Cfg::PITCH + cb * 64;
+            s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(C1V_LDS_PTR(s16x4_t, sw + g2off_lo + imm));
+            s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(C1V_LDS_PTR(s16x4_t, sw + g2off_hi + imm));
             return make_uint4(__builtin_bit_cast(uint2, lo).x, __builtin_bit_cast(uint2, lo).y,
                               __builtin_bit_cast(uint2, hi).x, __builtin_bit_cast(uint2, hi).y);
         };
@@ -358,7 +364,7 @@ void vocab_stream_kernel(const bf16_raw* __restrict__ yhat, int M, const bf16_ra
                 if (q == Q1 - 1 && t + 1 < t_end) {
                     const char* swn1 = smem + ((t + 1 - t_begin) % VS_STAGES) * Cfg::STAGE;
 #pragma unroll
-                    for (int f = 0; f < G1; ++f) a1[0][f] = *(const uint4*)(swn1 + vs_off<CB>((f & 1) * 32 + l31, 2 * (f >> 1) + h));
+                    for (int f = 0; f < G1; ++f) a1[0][f] = ld1_at(swn1, f & 1, f >> 1);
                 }
             }
 #endif
@@ -416,7 +422,7 @@ void vocab_stream_kernel(const bf16_raw* __restrict__ yhat, int M, const bf16_ra
                 // first GEMM1 fragments of tile t+1, behind the last batch
                 if (q == Q2 - 1 && t + 1 < t_end) {
 #pragma unroll
-                    for (int f = 0; f < G1; ++f) a1[0][f] = *(const uint4*)(swn + vs_off<CB>((f & 1) * 32 + l31, 2 * (f >> 1) + h));
+                    for (int f = 0; f < G1; ++f) a1[0][f] = ld1_at(swn, f & 1, f >> 1);
                 }
 #endif
                 __builtin_amdgcn_sched_barrier(0);
