@@ -56,6 +56,16 @@ __device__ __forceinline__ void c1v_glds16(const void* gsrc, uint32_t lds_addr) 
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(a), "v"(gsrc) : "memory", "m0");
 }
 
+// Same request with the address split into a wave-uniform base (SGPR pair) and a 32-bit per-lane byte offset: no 64-bit
+// VALU addition per request when only the base changes from one request to the next.
+__device__ __forceinline__ void c1v_glds16_so(const void* sbase, uint32_t voff, uint32_t lds_addr) {
+    const uint32_t a = __builtin_amdgcn_readfirstlane(lds_addr);
+    const uint64_t b = (uint64_t)(uintptr_t)sbase;
+    const uint32_t blo = __builtin_amdgcn_readfirstlane((uint32_t)b), bhi = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32));
+    const uint64_t bs = ((uint64_t)bhi << 32) | blo;
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(a), "v"(voff), "s"(bs) : "memory", "m0");
+}
+
 // Touch the 64-byte lines [1, LINES] of the kernel-argument segment with independent scalar loads and wait once: the
 // compiler fetches by-value argument structs lazily, one cold line (a trip to memory, ~1k cycles) at a time, wherever a
 // field is first used; after this every such fetch hits the scalar cache.  (HIP appends its hidden arguments to the

@@ -150,7 +150,7 @@ void vocab_stream_kernel(const bf16_raw* __restrict__ yhat, int M, const bf16_ra
     }
     auto stage_piece = [&](int t, int stage, int i) {
         const char* tile = (const char*)w + (int64_t)t * VS_BN * Cfg::ROWB;
-        c1v_glds16(tile + src_off[i], c1v_lds_addr(smem + stage * Cfg::STAGE + (wave + 4 * i) * 1024));
+        c1v_glds16_so(tile, (uint32_t)src_off[i], c1v_lds_addr(smem + stage * Cfg::STAGE + (wave + 4 * i) * 1024));
     };
     auto stage_tile = [&](int t, int stage) {
 #pragma unroll
