@@ -245,10 +245,9 @@ void vocab_stream_kernel(const bf16_raw* __restrict__ yhat, int M, const bf16_ra
 #pragma unroll
         for (int f = 0; f < G1; ++f) a1[0][f] = ld1_at(smem, f & 1, f >> 1);
     }
-    f32x16_t S[MB][2];                             // GEMM1 accumulators: the two 32-row blocks of the vocabulary tile
     // VALU stage on accumulator regs [r0, r1) of block nb of the tile whose first vocabulary row is pn0 (tile index pt):
     // exp2 (+ tail mask) / running sum / running arg-max.  tailc: the tile hangs over the end of the vocabulary.
-    auto post = [&](int nb, int r0, int r1, int pn0, int mb0, int mb1, auto tailc) {
+    auto post = [&](f32x16_t (&S)[MB][2], int nb, int r0, int r1, int pn0, int mb0, int mb1, auto tailc) {
         constexpr bool TAIL = decltype(tailc)::value;
 #pragma unroll
         for (int mb = mb0; mb < mb1; ++mb) {
@@ -314,7 +313,9 @@ void vocab_stream_kernel(const bf16_raw* __restrict__ yhat, int M, const bf16_ra
                               __builtin_bit_cast(uint2, hi).x, __builtin_bit_cast(uint2, hi).y);
         };
 
-        // (no clearing of S: the first MFMA of every accumulator chain takes a constant-zero C operand)
+        // GEMM1 accumulators: the two 32-row blocks of the vocabulary tile (never cleared: the first MFMA of every chain takes a
+        // constant-zero C operand)
+        f32x16_t S[MB][2];
         f32x16_t zero16;
 #pragma unroll
         for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
@@ -373,8 +374,8 @@ void vocab_stream_kernel(const bf16_raw* __restrict__ yhat, int M, const bf16_ra
             if (q == Q1 - 1) VS_T(1);
         }
         // VALU stage on both blocks
-        post(0, 0, 16, n0, 0, MB, tailc);
-        post(1, 0, 16, n0, 0, MB, tailc);
+        post(S, 0, 0, 16, n0, 0, MB, tailc);
+        post(S, 1, 0, 16, n0, 0, MB, tailc);
 
         if constexpr (MODE == VS_ACCUM) {
             bf16x8_t pf[2][2];
