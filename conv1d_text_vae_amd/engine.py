@@ -516,8 +516,10 @@ class VAEEngine:
             fblk[0] += (count + L.CHUNK - 1) // L.CHUNK
             return t
 
+        wgrad_rows = int(os.environ.get('C1V_WGRAD_ROWS', '384'))      # sample rows per wgrad split (measured at C2: 384 < 512 < 768)
+
         def row_splits(rows: int) -> int:
-            return int(max(1, min(32, rows // 512)))
+            return int(max(1, min(32, rows // wgrad_rows)))
 
         def conv_wgrad(X: Buf, dO: Buf, wname: str, bname: str, C_in: int, F: int, flip: int, tap_stride, si, sj, frozen=False):
             rows = B * X.pitch
