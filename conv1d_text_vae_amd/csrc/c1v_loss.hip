@@ -526,7 +526,12 @@ __global__ __launch_bounds__(256) void xent_finish_kernel(const float* __restric
         if (lane == 0) xent_rows[m] = 0.0f;
         if (dy.data != nullptr) {
             const int64_t drow0 = (int64_t)b * dy.bstride + (int64_t)(dy.off + t) * dy.cp;
-            for (int c = lane; c < V; c += 64) store_any(dy.data, dy.dtype, drow0 + c, 0.0f);
+            // (bf16 rows of whole 16-byte words: one store per lane; the channel padding behind V is zero anyway)
+            if (dy.dtype == C1V_BF16 && ((((uintptr_t)dy.data) & 15) == 0) && (dy.cp & 7) == 0 && (dy.bstride & 7) == 0 && ((V + 7) & ~7) <= dy.cp) {
+                for (int c = lane * 8; c < V; c += 512) *(uint4*)((bf16_raw*)dy.data + drow0 + c) = make_uint4(0u, 0u, 0u, 0u);
+            } else {
+                for (int c = lane; c < V; c += 64) store_any(dy.data, dy.dtype, drow0 + c, 0.0f);
+            }
         }
         return;
     }
