@@ -114,3 +114,21 @@ def test_data_parallel_gradient_equals_full_batch_gradient():
         ret = m.dict()
         mp.spawn(_dp_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
         assert all(ret[r] for r in range(world))
+
+
+def test_bench_spawns_its_own_ranks_and_relays_one_json_line():
+    """`python bench.py --gpus 2` without torchrun (how the round-end driver starts it): the parent must start both ranks
+    before touching a GPU, the ranks must find each other on 127.0.0.1, and stdout must carry exactly rank 0's line.
+    `--dry-run` swaps the GPU work for a gloo all-reduce, so this runs without a GPU."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    p = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--dry-run'], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    rec = json.loads(lines[0])
+    assert rec == {'metric': 'dry_run', 'n_gpus': 2, 'rank_sum': 3.0}
