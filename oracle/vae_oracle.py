@@ -357,9 +357,14 @@ def vae_loss_bwd(y_pred, W_vocab, target_ids, z_mean, z_log_var, cache, tau=TAU)
 
 
 def train_forward_backward(geom: VAEGeometry, params, W_vocab, x, target_ids, eps,
-                           mask_e=None, mask_d=None, frozen_encoder: bool = False):
+                           mask_e=None, mask_d=None, frozen_encoder: bool = False, decisions: Optional[dict] = None):
     """One training forward+backward of FullVAE (:1320) with injected eps / dropout masks.
-    Returns (loss, grads dict, activations dict)."""
+    Returns (loss, grads dict, activations dict).
+
+    decisions (error attribution in the bf16 parity tests, not reference behaviour): the ReLU / max-pool choices of
+    ANOTHER run of the same step -- `enc_sel_i` bool [B, L_pool, F] (odd element chosen), `enc_on_i` bool [B, L_pool, F]
+    (chosen element > 0), `dec_on_i` bool [B, L, F], `dense_on` bool [B, n_t*width] -- replace this run's own choices in
+    the backward pass, so that what is left of the difference between the two gradients is rounding, not flipped choices."""
     c: dict = {}
     z_mean, z_log_var = encoder_forward(geom, params, x, mask_e, c)
     z = sampling(z_mean, z_log_var, eps)
@@ -378,12 +383,12 @@ def train_forward_backward(geom: VAEGeometry, params, W_vocab, x, target_ids, ep
     g = full
     for i in reversed(range(len(geom.dec_filters))):
         g = upsample2_bwd(g)
-        g = g * (c['dec_act_%d' % i] > 0)
+        g = g * (decisions['dec_on_%d' % i] if decisions is not None else (c['dec_act_%d' % i] > 0))
         name = 'deconv_decoder_%d_deconv1d_part2' % (i + 1)
         g, dWt, db = deconv1d_valid_bwd(c['dec_in_%d' % i], params[name + '/kernel'], g)
         grads[name + '/kernel'] = dWt
         grads[name + '/bias'] = db
-    g = g.reshape(g.shape[0], -1) * (c['dense_act'] > 0)
+    g = g.reshape(g.shape[0], -1) * (decisions['dense_on'] if decisions is not None else (c['dense_act'] > 0))
     grads['deconv_decoder_dense/kernel'] = c['zd'].T @ g
     grads['deconv_decoder_dense/bias'] = g.sum(axis=0)
     dzd = g @ params['deconv_decoder_dense/kernel'].T
@@ -402,8 +407,11 @@ def train_forward_backward(geom: VAEGeometry, params, W_vocab, x, target_ids, ep
     g = dflat.reshape(c['pool_shape'])
     for i in reversed(range(len(geom.n_filters))):
         act = c['enc_act_%d' % i]
-        g = maxpool2_bwd(g, c['enc_sel_%d' % i], act.shape[1])
-        g = g * (act > 0)
+        if decisions is not None:
+            g = maxpool2_bwd(g * decisions['enc_on_%d' % i], decisions['enc_sel_%d' % i], act.shape[1])
+        else:
+            g = maxpool2_bwd(g, c['enc_sel_%d' % i], act.shape[1])
+            g = g * (act > 0)
         name = 'encoder_conv1d_%d' % (i + 1)
         g, dW, db = conv1d_valid_bwd(c['enc_in_%d' % i], params[name + '/kernel'], g)
         grads[name + '/kernel'] = dW

@@ -41,6 +41,30 @@ def rel_l2(a, b):
     return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)
 
 
+def engine_decisions(eng):
+    """ReLU / max-pool choices the engine's backward pass of the last step acted on, in the layout of the oracle's
+    `decisions` argument: read back from the pool-selection bytes and from the stored (post-ReLU) activations."""
+    g = eng.g
+    nl, nd = len(g.n_filters), len(g.dec_filters)
+    B = eng.B
+    d = {}
+    for l in range(nl):
+        d['enc_sel_%d' % l] = eng.sel[l].cpu().numpy().astype(bool)
+        if l == nl - 1:
+            pooled = eng.H.t[:B * eng.flat_p].view(B, eng.flat_p)[:, :eng.flat].reshape(B, g.enc_len_pool[l], g.n_filters[l])
+        else:
+            pooled = eng.Xe[l + 1].valid()
+        d['enc_on_%d' % l] = (pooled.float() > 0).cpu().numpy()
+    d['dense_on'] = (eng.Xd[0].valid().float() > 0).cpu().numpy().reshape(B, -1)
+    for i in range(nd):
+        nxt = eng.Xf if i == nd - 1 else eng.Xd[i + 1]
+        on = (nxt.valid().float()[:, ::2] > 0).cpu().numpy()
+        full = np.zeros((B, g.dec_len_deconv[i], g.dec_filters[i]), dtype=bool)      # rows cut off by the crop: no gradient
+        full[:, :on.shape[1]] = on[:, :g.dec_len_deconv[i]]
+        d['dec_on_%d' % i] = full
+    return d
+
+
 # ------------------------------------------------------------------------------------------------ C4
 def test_c4_geometry_is_the_survey_shape_walk():
     _, _, geometry, _ = _mods()
@@ -90,13 +114,24 @@ def test_c4_deep_stack_matches_oracle_at_reduced_batch(dtype):
         assert rel_err(got, ref) < (tol if dtype == 'f32' else 3e-2), (k_, rel_err(got, ref))
     assert abs(eng.loss() - loss) < (1e-4 if dtype == 'f32' else 1e-2) * max(1.0, abs(loss)), (eng.loss(), loss)
     gg = eng.get_grads()
+    if dtype == 'bf16':
+        # Measured exception to "gradients at the activation tolerance" (DESIGN.md section 2): a bf16 forward pass moves every
+        # pre-activation by ~0.4 % of its scale, which flips the ReLU / max-pool choice of the ~0.3 % of elements that close
+        # to a tie; a fraction f of flipped choices costs sqrt(f) ~ 5 % of a gradient's Frobenius norm PER LAYER crossed
+        # (10 layers: ~16 %).  The flips are the whole of it: against the oracle's backward pass run on the SAME choices the
+        # gradients agree to bf16 rounding.
+        _, same_choice, _ = O.train_forward_backward(og, p64, Wv.astype(np.float64), x.astype(np.float64), ids,
+                                                     eps.astype(np.float64), me, md, decisions=engine_decisions(eng))
     for k_, ref in grads.items():
         e2, em = rel_l2(gg[k_], ref), rel_err(gg[k_], ref)
-        print(dtype, 'grad', k_, 'rel-L2 %.3e max-rel %.3e' % (e2, em))
         if dtype == 'f32':
+            print(dtype, 'grad', k_, 'rel-L2 %.3e max-rel %.3e' % (e2, em))
             assert em < 5e-4, (k_, em)
         else:
-            assert e2 < 0.15, (k_, e2)
+            e2s = rel_l2(gg[k_], same_choice[k_])
+            print(dtype, 'grad', k_, 'rel-L2 %.3e (same ReLU / pool choices: %.3e)' % (e2, e2s))
+            assert e2 < 0.22, (k_, e2)
+            assert e2s < 2e-2, (k_, e2s)
 
 
 def test_c4_full_size_step_f32_and_bf16_agree_and_train():
