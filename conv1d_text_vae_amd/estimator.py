@@ -360,9 +360,8 @@ class Conv1dTextVAE(BaseEstimator, TransformerMixin, ClassifierMixin):
         self.check_params(**self.get_params(deep=False))
         self.check_embeddings()
         self.check_texts_param(X, 'X')
-        if y is None:
-            y_ = X
-        else:
+        y_ = X
+        if y is not None:                                            # y = None: plain auto-encoding of X
             self.check_texts_param(y, 'y')
             if len(y) != len(X):
                 raise ValueError('Length of `X` does not equal to length of `y`! {0} != {1}.'.format(len(X), len(y)))
@@ -370,13 +369,12 @@ class Conv1dTextVAE(BaseEstimator, TransformerMixin, ClassifierMixin):
         if self.use_batch_norm:
             raise NotImplementedError('use_batch_norm=True is not available on the HIP path (it is off by default in the '
                                       'reference and needs cross-GPU batch statistics).')
-        if self.tokenizer is None:
-            self.tokenizer = DefaultTokenizer()
+        self.tokenizer = self.tokenizer or DefaultTokenizer()
+        # the LAST round(n * validation_fraction) pairs are the evaluation set (:201-217); both parts must be non-empty
         n_eval_set = int(round(len(X) * self.validation_fraction))
-        if n_eval_set < 1:
-            raise ValueError('`validation_fraction` is too small! There are no samples for evaluation!')
-        if n_eval_set >= len(X):
-            raise ValueError('`validation_fraction` is too large! There are no samples for training!')
+        if not 1 <= n_eval_set < len(X):
+            raise ValueError('`validation_fraction` is too small! There are no samples for evaluation!' if n_eval_set < 1 else
+                             '`validation_fraction` is too large! There are no samples for training!')
         special_symbols = self._special_symbols(none_if_empty=True)
         if self.warm_start:
             self.check_is_fitted()
@@ -755,18 +753,17 @@ class Conv1dTextVAE(BaseEstimator, TransformerMixin, ClassifierMixin):
 
     @staticmethod
     def check_texts_param(param_value, param_name: str):
-        if (not isinstance(param_value, list)) and (not isinstance(param_value, tuple)) and \
-                (not isinstance(param_value, np.ndarray)):
+        """A list, a tuple or a 1-D array of string-like items; the reference's messages (:675-688)."""
+        kinds = (list, tuple, np.ndarray)
+        if not isinstance(param_value, kinds):
             raise ValueError('The parameter `{0}` is wrong! Expected `{1}`, `{2}` or 1-D `{3}`, got `{4}`.'.format(
-                param_name, type([1, 2]), type((1, 2)), type(np.array([1, 2])), type(param_value)))
-        if isinstance(param_value, np.ndarray):
-            if len(param_value.shape) != 1:
-                raise ValueError('The parameter `{0}` is wrong! Expected 1-D array, got {1}-D array.'.format(
-                    param_name, len(param_value.shape)))
-        for idx in range(len(param_value)):
-            if (not hasattr(param_value[idx], 'split')) or (not hasattr(param_value[idx], 'strip')):
-                raise ValueError('Item {0} of the parameter `{1}` is wrong! This item is not string!'.format(
-                    idx, param_name))
+                param_name, *kinds, type(param_value)))
+        n_dims = param_value.ndim if isinstance(param_value, np.ndarray) else 1
+        if n_dims != 1:
+            raise ValueError('The parameter `{0}` is wrong! Expected 1-D array, got {1}-D array.'.format(param_name, n_dims))
+        for idx, item in enumerate(param_value):
+            if not (hasattr(item, 'split') and hasattr(item, 'strip')):
+                raise ValueError('Item {0} of the parameter `{1}` is wrong! This item is not string!'.format(idx, param_name))
 
     @staticmethod
     def check_params(**params):

@@ -16,21 +16,28 @@ from xml.sax.saxutils import unescape
 
 
 class BaseTokenizer:
+    """Interface of the reference's tokenizers (:28-43): word spans as (begin, end) character offsets."""
+
     def tokenize_into_words(self, src: str) -> List[Tuple[int, int]]:
-        raise NotImplemented
+        raise NotImplementedError
 
     @staticmethod
     def tokenize_into_characters(src: str, bounds_of_words: List[Tuple[int, int]]) -> List[str]:
-        characters_list = []
-        start_pos = 0
-        for bounds_of_cur_word in bounds_of_words:
-            if bounds_of_cur_word[0] > start_pos:
-                characters_list.append('\n' if '\n' in src[start_pos:bounds_of_cur_word[0]] else ' ')
-            characters_list += list(src[bounds_of_cur_word[0]:bounds_of_cur_word[1]])
-            start_pos = bounds_of_cur_word[1]
-        if start_pos < len(src):
-            characters_list.append('\n' if '\n' in src[start_pos:] else ' ')
-        return characters_list
+        """The characters of the words, with ONE separator for whatever lies between two words (and before the first /
+        after the last): a line feed if that stretch contains one, otherwise a blank."""
+        def separator(begin: int, end: int) -> List[str]:
+            if end <= begin:
+                return []
+            return ['\n'] if '\n' in src[begin:end] else [' ']
+
+        chars: List[str] = []
+        cursor = 0
+        for begin, end in bounds_of_words:
+            chars.extend(separator(cursor, begin))
+            chars.extend(src[begin:end])
+            cursor = end
+        chars.extend(separator(cursor, len(src)))
+        return chars
 
 
 _CLASSES = {}
@@ -80,45 +87,36 @@ class DefaultTokenizer(BaseTokenizer):
             self.re_for_special_symbols = None
 
     def tokenize_into_words(self, src: str) -> List[Tuple[int, int]]:
-        prep = src.strip()
-        if len(prep) == 0:
+        """Spans of the NIST tokens of `src`; every occurrence of a special symbol is a token of its own and the text
+        between two occurrences is tokenised separately (:57-99)."""
+        if not src.strip():
             return []
         if self.re_for_special_symbols is None:
-            return self.__tokenize_text(src)
-        bounds_of_subphrases = []
-        start_pos = 0
-        for search_res in self.re_for_special_symbols.finditer(src):
-            if (search_res.start() < 0) or (search_res.end() < 0):
-                break
-            bounds_of_subphrases.append(('', (start_pos, search_res.start())))
-            bounds_of_subphrases.append((src[search_res.start():search_res.end()], (search_res.start(), search_res.end())))
-            start_pos = search_res.end()
-        if start_pos < len(src):
-            bounds_of_subphrases.append(('', (start_pos, len(src))))
-        bounds_of_tokens = []
-        for cur_subphrase in bounds_of_subphrases:
-            if len(cur_subphrase[0]) == 0:
-                text = src[cur_subphrase[1][0]:cur_subphrase[1][1]]
-                for cur_token in self.__tokenize_text(text):
-                    bounds_of_tokens.append((cur_subphrase[1][0] + cur_token[0], cur_subphrase[1][0] + cur_token[1]))
-            else:
-                bounds_of_tokens.append((cur_subphrase[1][0], cur_subphrase[1][1]))
-        return bounds_of_tokens
+            return self._token_spans(src, 0, len(src))
+        spans: List[Tuple[int, int]] = []
+        cursor = 0
+        for hit in self.re_for_special_symbols.finditer(src):
+            spans += self._token_spans(src, cursor, hit.start())
+            spans.append((hit.start(), hit.end()))
+            cursor = hit.end()
+        return spans + self._token_spans(src, cursor, len(src))
 
-    def __tokenize_text(self, src: str) -> List[Tuple[int, int]]:
-        prep = src.strip()
-        if len(prep) == 0:
-            return []
-        bounds_of_tokens = []
-        end_pos = 0
-        for cur_token in filter(lambda it2: len(it2) > 0,
-                                map(lambda it1: it1.strip(), self.tokenizer.international_tokenize(src))):
-            start_pos = src.find(cur_token, end_pos)
-            if start_pos < 0:
-                raise ValueError('Token `{0}` cannot be found in the text `{1}`!'.format(cur_token, src))
-            end_pos = start_pos + len(cur_token)
-            bounds_of_tokens.append((start_pos, end_pos))
-        return bounds_of_tokens
+    def _token_spans(self, src: str, begin: int, end: int) -> List[Tuple[int, int]]:
+        """Where the tokens of src[begin:end] sit in `src`: the tokenizer returns strings, so each one is looked up from
+        the end of the previous one onwards (:101-114)."""
+        piece = src[begin:end]
+        spans: List[Tuple[int, int]] = []
+        cursor = 0
+        for token in self.tokenizer.international_tokenize(piece):
+            token = token.strip()
+            if not token:
+                continue
+            at = piece.find(token, cursor)
+            if at < 0:
+                raise ValueError('Token `{0}` cannot be found in the text `{1}`!'.format(token, piece))
+            cursor = at + len(token)
+            spans.append((begin + at, begin + cursor))
+        return spans
 
     def __getstate__(self):
         return {'special_symbols': self.special_symbols}
