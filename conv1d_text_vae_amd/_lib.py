@@ -18,6 +18,11 @@ PACK_TILE = 64          # C1V_PACK_TILE
 ROW_STORE, ROW_POOL2, ROW_UP2, ROW_PAIRSUM, ROW_UNPOOL, ROW_LATENT_BWD = 0, 1, 2, 3, 4, 5
 
 
+def fused_width(kp: int) -> bool:
+    """Row widths (elements) the fused bf16 stream kernel is instantiated for (vs_fused_width in c1v_loss.hip)."""
+    return kp == 32 or (kp % 64 == 0 and 64 <= kp <= 320)
+
+
 class Seq(C.Structure):
     _fields_ = [('data', C.c_void_p), ('dtype', C.c_int32), ('batch', C.c_int32), ('bstride', C.c_int64),
                 ('off', C.c_int32), ('len', C.c_int32), ('cp', C.c_int32), ('c', C.c_int32)]
@@ -149,6 +154,15 @@ class VocabArgmaxArgs(C.Structure):
                 ('idx', C.c_void_p), ('logits', C.c_void_p), ('n_chunk', C.c_int32)]
 
 
+class VocabArgmaxNoallocArgs(C.Structure):
+    _fields_ = [('q', C.c_void_p), ('M', C.c_int32), ('kp', C.c_int32), ('w', C.c_void_p), ('N', C.c_int32),
+                ('n_pad', C.c_int32), ('n_base', C.c_int32), ('score', C.c_void_p), ('idx', C.c_void_p)]
+
+
+NOALLOC_SCRATCH_BYTES = 8 << 20
+NOALLOC_MAX_QUERIES = NOALLOC_SCRATCH_BYTES // 8 // 128 * 128
+
+
 class VocabTopnArgs(C.Structure):
     _fields_ = [('q', C.c_void_p), ('dtype', C.c_int32), ('M', C.c_int32), ('kp', C.c_int32), ('w', C.c_void_p),
                 ('N', C.c_int32), ('n_base', C.c_int32), ('logits', C.c_void_p), ('ld', C.c_int64),
@@ -194,6 +208,7 @@ SYMBOLS = {
     'c1v_eos_truncate_normalize_f64': ([C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                         C.c_void_p], C.c_int),
     'c1v_vocab_argmax': ([_P(VocabArgmaxArgs), C.c_void_p], C.c_int),
+    'c1v_vocab_argmax_noalloc': ([_P(VocabArgmaxNoallocArgs), C.c_void_p], C.c_int),
     'c1v_vocab_topn': ([_P(VocabTopnArgs), C.c_void_p], C.c_int),
     'c1v_argmax_merge': ([C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p], C.c_int),
     'c1v_philox_normal': ([C.c_void_p, C.c_int64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint64,

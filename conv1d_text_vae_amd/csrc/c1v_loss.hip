@@ -879,12 +879,18 @@ static int launch_vs(const bf16_raw* yhat, int M, const bf16_raw* w, int N, int 
     return launch_vs_mb<CB, MODE, 1>(yhat, M, w, N, n_base, splits, ut, m_pad, ones_col, ps, pi, ctl, st);
 }
 
+// widths (elements per row of Yhat / W) the fused stream kernel is instantiated for
+static inline bool vs_fused_width(int kp) { return kp == 32 || (kp % 64 == 0 && kp >= 64 && kp <= 320); }
+
 template <int MODE>
 static int dispatch_vs(int kp, const bf16_raw* yhat, int M, const bf16_raw* w, int N, int n_base, int splits, float* ut, int m_pad, int ones_col,
                        float* ps, int* pi, const int* ctl, hipStream_t st) {
     switch (kp) {
         case 32:  return launch_vs<1, MODE>(yhat, M, w, N, n_base, splits, ut, m_pad, ones_col, ps, pi, ctl, st);
         case 64:  return launch_vs<2, MODE>(yhat, M, w, N, n_base, splits, ut, m_pad, ones_col, ps, pi, ctl, st);
+        case 128: return launch_vs<4, MODE>(yhat, M, w, N, n_base, splits, ut, m_pad, ones_col, ps, pi, ctl, st);
+        case 192: return launch_vs<6, MODE>(yhat, M, w, N, n_base, splits, ut, m_pad, ones_col, ps, pi, ctl, st);
+        case 256: return launch_vs<8, MODE>(yhat, M, w, N, n_base, splits, ut, m_pad, ones_col, ps, pi, ctl, st);
         case 320: return launch_vs<10, MODE>(yhat, M, w, N, n_base, splits, ut, m_pad, ones_col, ps, pi, ctl, st);
         default: return 1;   // no fused instantiation for this width
     }
@@ -952,8 +958,7 @@ extern "C" int c1v_cos_softmax_accum(const c1v_xent_accum_args* a, void* stream)
     hipStream_t st = (hipStream_t)stream;
     if (a->dtype == C1V_BF16) {
         if (a->live_ctl) {
-            const bool fused = a->kp == 32 || a->kp == 64 || a->kp == 320;
-            C1V_REQUIRE(fused, "cos_softmax_accum: live_ctl needs the fused stream kernel (kp = 32, 64 or 320; got %d)", a->kp);
+            C1V_REQUIRE(vs_fused_width(a->kp), "cos_softmax_accum: live_ctl needs the fused stream kernel (kp = 32 or a multiple of 64 up to 320; got %d)", a->kp);
         }
         int rc = a->need_u
             ? dispatch_vs<VS_ACCUM>(a->kp, (const bf16_raw*)a->yhat, a->M, (const bf16_raw*)a->w, a->N, 0, a->splits, a->ut, a->m_pad, a->ones_col, nullptr, nullptr, a->live_ctl, st)
@@ -1069,6 +1074,73 @@ extern "C" int c1v_vocab_topn(const c1v_vocab_topn_args* a, void* stream) {
     int rc = c1v_launch_nt(a->dtype, p, st);
     if (rc) return rc;
     hipLaunchKernelGGL(row_topn_kernel, dim3((unsigned)c1v_cdiv(a->M, 4)), dim3(256), 0, st, a->logits, a->M, a->ld, a->N, a->n_base, a->topn, a->score, a->idx);
+    C1V_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// c1v_vocab_argmax for callers that cannot allocate: the per-split partial (score, index) rows live in a file-scope
+// device array instead of caller scratch.  Every GPU holds its own copy of the array at its own address, looked up once
+// per device with hipGetSymbolAddress; host code only ever uses that pointer (the array's NAME is a host-side stand-in,
+// not a device address).
+// ------------------------------------------------------------------------------------------------------
+static __device__ __align__(256) unsigned char c1v_noalloc_scratch[C1V_NOALLOC_SCRATCH_BYTES];
+
+#include <mutex>
+static std::mutex g_noalloc_mu;
+static void* g_noalloc_ptr[C1V_NOALLOC_MAX_DEVICES];          // device address of c1v_noalloc_scratch, per device
+
+static int noalloc_scratch_ptr(void** out) {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess || dev < 0 || dev >= C1V_NOALLOC_MAX_DEVICES) {
+        c1v_set_error("vocab_argmax_noalloc: cannot identify the current device (%s, device %d)", hipGetErrorString(e), dev);
+        return -1;
+    }
+    std::lock_guard<std::mutex> lock(g_noalloc_mu);
+    if (g_noalloc_ptr[dev] == nullptr) {
+        void* p = nullptr;
+        e = hipGetSymbolAddress(&p, HIP_SYMBOL(c1v_noalloc_scratch));      // with device `dev` current: ITS copy of the array
+        if (e != hipSuccess || p == nullptr) {
+            c1v_set_error("vocab_argmax_noalloc: hipGetSymbolAddress failed on device %d: %s", dev, hipGetErrorString(e));
+            return -1;
+        }
+        g_noalloc_ptr[dev] = p;
+    }
+    *out = g_noalloc_ptr[dev];
+    return 0;
+}
+
+extern "C" int c1v_vocab_argmax_noalloc(const c1v_vocab_argmax_noalloc_args* a, void* stream) {
+    C1V_REQUIRE(a && a->q && a->w && a->score && a->idx, "vocab_argmax_noalloc: null argument");
+    C1V_REQUIRE(a->M > 0 && a->N > 0, "vocab_argmax_noalloc: bad shape M=%d N=%d", a->M, a->N);
+    C1V_REQUIRE(vs_fused_width(a->kp),
+                "vocab_argmax_noalloc: kp = %d has no fused bf16 kernel (32 or a multiple of 64 up to 320); use c1v_vocab_argmax with a logits scratch", a->kp);
+    C1V_REQUIRE(a->n_pad % VS_BN == 0 && a->n_pad >= a->N, "vocab_argmax_noalloc: n_pad (%d) must be a multiple of %d covering N", a->n_pad, VS_BN);
+    const int64_t m_pad = c1v_cdiv(a->M, VS_BM) * VS_BM;
+    const int64_t per_split = m_pad * (int64_t)(sizeof(float) + sizeof(int32_t));
+    C1V_REQUIRE(per_split <= (int64_t)C1V_NOALLOC_SCRATCH_BYTES,
+                "vocab_argmax_noalloc: M = %d queries need %lld bytes of partial results, the static scratch holds %u (at most %d queries)",
+                a->M, (long long)per_split, (unsigned)C1V_NOALLOC_SCRATCH_BYTES, C1V_NOALLOC_MAX_QUERIES);
+    // vocabulary splits: enough workgroups to fill the chip (as the Python host picks them), capped by what the scratch holds
+    int64_t splits = (2 * 256) / (m_pad / VS_BM);
+    const int64_t tiles = a->n_pad / VS_BN;
+    if (splits > tiles) splits = tiles;
+    if (splits > 16) splits = 16;
+    if (splits > (int64_t)C1V_NOALLOC_SCRATCH_BYTES / per_split) splits = (int64_t)C1V_NOALLOC_SCRATCH_BYTES / per_split;
+    if (splits < 1) splits = 1;
+    void* base = nullptr;
+    if (noalloc_scratch_ptr(&base)) return -1;
+    float* part_score = (float*)base;
+    int32_t* part_idx = (int32_t*)((char*)base + splits * m_pad * (int64_t)sizeof(float));
+    hipStream_t st = (hipStream_t)stream;
+    // every (split, row < m_pad) cell of the partial results is written by the stream kernel before the merge reads it, so
+    // nothing of the previous call's contents has to be cleared
+    int rc = dispatch_vs<VS_ARGMAX>(a->kp, (const bf16_raw*)a->q, a->M, (const bf16_raw*)a->w, a->N, a->n_base, (int)splits, nullptr, (int)m_pad, 0,
+                                    part_score, part_idx, nullptr, st);
+    if (rc != 0) { if (rc > 0) c1v_set_error("vocab_argmax_noalloc: no fused kernel for kp = %d", a->kp); return rc < 0 ? rc : -1; }
+    hipLaunchKernelGGL(argmax_merge_kernel, dim3((unsigned)c1v_cdiv(a->M, 256)), dim3(256), 0, st, part_score, part_idx, (int)splits, m_pad, a->M,
+                       a->score, a->idx);
     C1V_LAUNCH_CHECK();
     return 0;
 }

@@ -63,6 +63,19 @@ class Buf:
         return rows[:, self.off:self.off + self.len, :self.c]
 
 
+_warned_unfused = set()
+
+
+def _warn_unfused(kp: int):
+    """Once per width: the fused stream kernel has no instantiation for it, so the loss / arg-max run as separate GEMMs
+    through a materialised logits scratch (slower, up to 256 MB of scratch)."""
+    if kp not in _warned_unfused:
+        _warned_unfused.add(kp)
+        import sys
+        print('c1dvae: no fused vocabulary kernel for a row width of %d elements (embedding size above 318); using the '
+              'unfused GEMM path through a logits scratch' % kp, file=sys.stderr)
+
+
 def _null_seq() -> L.Seq:
     return L.Seq(None, 0, 0, 0, 0, 0, 0, 0)
 
@@ -251,8 +264,10 @@ class VAEEngine:
         host[:self.N, :self.V] = W
         host[:self.N, self.ones_col] = 1.0
         self.w_vocab = torch.from_numpy(host).to(self.dev).to(self.tdt).contiguous()
-        fused = self.code == L.BF16 and self.kp in (32, 64, 320)
+        fused = self.code == L.BF16 and L.fused_width(self.kp)
         tiles = self.n_pad // 64
+        if self.code == L.BF16 and not fused:
+            _warn_unfused(self.kp)
         if fused:
             want = max(1, (int(os.environ.get('C1V_WG_WAVES', '1')) * 256) // max(1, self.m_pad // 128))
             self.x_splits = max(1, min(tiles, want, 16))
@@ -992,6 +1007,7 @@ class VAEEngine:
 
     def decode_latent(self, z: torch.Tensor) -> torch.Tensor:
         """vae_decoder_.predict_on_batch(z): z [B, latent] fp32 -> y [B, T_out, V] fp32."""
+        self._ensure_packed()               # a train step leaves the refresh of the operand copies to the next prologue
         self.mlv_parts.zero_()
         self.mlv[:, :self.D].copy_(z)
         self._run(self.ops_lat_infer + self.ops_dec)
@@ -1023,7 +1039,9 @@ class VocabDecoder:
         self.Mmax = int(max_queries)
         self.m_pad = _pad(self.Mmax, 128)
         self.q = torch.zeros((self.m_pad + L.SLACK_ROWS) * self.kp, dtype=self.tdt, device=self.dev)
-        fused = self.code == L.BF16 and self.kp in (32, 64, 320)
+        fused = self.code == L.BF16 and L.fused_width(self.kp)
+        if self.code == L.BF16 and not fused:
+            _warn_unfused(self.kp)
         tiles = self.n_pad // 64
         self.splits = max(1, min(tiles, (2 * 256) // max(1, self.m_pad // 128), 16)) if fused else 1
         self.part_score = torch.zeros(self.splits * self.m_pad, dtype=torch.float32, device=self.dev)

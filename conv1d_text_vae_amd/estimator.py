@@ -36,7 +36,11 @@ EPSILON = 1e-7                    # keras.backend.epsilon()
 FITTED_ATTRIBUTES = ['input_text_size_', 'output_text_size_', 'input_vector_size_', 'output_vector_size_',
                      'vae_encoder_', 'vae_decoder_', 'generator_encoder_', 'generator_decoder_',
                      'output_text_size_in_characters_', 'target_char_index_', 'reverse_target_char_index_']
-ENCODER_PREFIXES = ('encoder_conv1d_', 'z_mean', 'z_log_var')
+# layers of 'EncoderForVAE' = Model(encoder_input, z_mean) (:1308): what `vae_encoder_` saves, pickles and hands to a warm start.
+# The z_log_var head belongs to neither saved model: after unpickling / in a warm start it is freshly initialised, as in the
+# reference (whose rebuilt graph gives it new random weights, frozen in a warm start, :1245).
+ENCODER_PREFIXES = ('encoder_conv1d_', 'z_mean')
+UNSAVED_PREFIXES = ('z_log_var',)
 
 
 def _npz_bytes(weights: Dict[str, np.ndarray]) -> bytes:
@@ -150,7 +154,7 @@ class VAEDecoderModel:
     predict = predict_on_batch
 
     def get_weights(self) -> Dict[str, np.ndarray]:
-        return {k: v for k, v in self.rt.weights().items() if not k.startswith(ENCODER_PREFIXES)}
+        return {k: v for k, v in self.rt.weights().items() if not k.startswith(ENCODER_PREFIXES + UNSAVED_PREFIXES)}
 
 
 class FullVAEModel:
@@ -369,7 +373,8 @@ class Conv1dTextVAE(BaseEstimator, TransformerMixin, ClassifierMixin):
         if self.use_batch_norm:
             raise NotImplementedError('use_batch_norm=True is not available on the HIP path (it is off by default in the '
                                       'reference and needs cross-GPU batch statistics).')
-        self.tokenizer = self.tokenizer or DefaultTokenizer()
+        if self.tokenizer is None:
+            self.tokenizer = DefaultTokenizer()
         # the LAST round(n * validation_fraction) pairs are the evaluation set (:201-217); both parts must be non-empty
         n_eval_set = int(round(len(X) * self.validation_fraction))
         if not 1 <= n_eval_set < len(X):
@@ -1039,10 +1044,10 @@ class Conv1dTextVAE(BaseEstimator, TransformerMixin, ClassifierMixin):
                         self.n_filters, self.kernel_size, self.latent_dim)
         weights = init_keras_weights(geom, seed)
         if vae_weights is not None:
-            missing = set(weights) - set(vae_weights)
+            missing = set(k for k in weights if not k.startswith(UNSAVED_PREFIXES)) - set(vae_weights)
             if missing:
                 raise ValueError('Weights are wrong! Missing arrays: {0}.'.format(sorted(missing)))
-            weights = {k: np.asarray(vae_weights[k], dtype=np.float32) for k in weights}
+            weights = {k: np.asarray(vae_weights[k], dtype=np.float32) if k in vae_weights else weights[k] for k in weights}
         if encoder_weights is not None:
             for k, v in encoder_weights.items():
                 if tuple(v.shape) != tuple(weights[k].shape):
@@ -1071,6 +1076,6 @@ class Conv1dTextVAE(BaseEstimator, TransformerMixin, ClassifierMixin):
                 print('  {0:<44s} {1:<24s} {2:>12d}'.format(name, str(tuple(shape)), n))
             print('  total parameters: {0}'.format(total))
         shapes = geom.keras_shapes()
-        table('ENCODER:', [(k, v) for k, v in shapes.items() if k.startswith(ENCODER_PREFIXES) and not k.startswith('z_log_var')])
-        table('DECODER:', [(k, v) for k, v in shapes.items() if not k.startswith(ENCODER_PREFIXES)])
+        table('ENCODER:', [(k, v) for k, v in shapes.items() if k.startswith(ENCODER_PREFIXES)])
+        table('DECODER:', [(k, v) for k, v in shapes.items() if not k.startswith(ENCODER_PREFIXES + UNSAVED_PREFIXES)])
         table('SEQUENCE-TO-SEQUENCE:', [(k, tuple(v.shape)) for k, v in generator.p.items()])

@@ -351,6 +351,25 @@ typedef struct c1v_vocab_topn_args {
     float* score; int32_t* idx;
 } c1v_vocab_topn_args;
 int c1v_vocab_topn(const c1v_vocab_topn_args*, void* stream);
+/* c1v_vocab_argmax (bf16, fused kernel) for callers that CANNOT ALLOCATE device memory -- code under HIP graph capture,
+ * tight serving loops, harnesses that forbid hipMalloc.  It has no counterpart in the reference (which has no device
+ * code at all).  The caller passes only inputs and outputs; the per-split partial (score, index) rows, which
+ * c1v_vocab_argmax takes as caller scratch, live in a static device array of C1V_NOALLOC_SCRATCH_BYTES inside the library
+ * (one copy per GPU, held until the process ends).  Limits: bf16 only; kp in {32, 64, 320}; at most
+ * C1V_NOALLOC_MAX_QUERIES rows per call (more is rejected with an error, nothing is launched); q [M][kp] bf16 and
+ * w [n_pad][kp] bf16 with rows >= N zero, as for c1v_vocab_argmax.  Results are identical to c1v_vocab_argmax's.
+ * The call allocates nothing and does not synchronise; the FIRST call on a device looks the array's address up
+ * (hipGetSymbolAddress), so make that call outside a graph capture.  All calls on one GPU share that GPU's array:
+ * calls that overlap on one GPU (two streams, two threads) race -- serialise them. */
+#define C1V_NOALLOC_SCRATCH_BYTES (8u << 20)
+#define C1V_NOALLOC_MAX_QUERIES   ((int32_t)(C1V_NOALLOC_SCRATCH_BYTES / 8 / 128 * 128))
+#define C1V_NOALLOC_MAX_DEVICES   64
+typedef struct c1v_vocab_argmax_noalloc_args {
+    const void* q; int32_t M, kp;
+    const void* w; int32_t N, n_pad; int32_t n_base;
+    float* score; int32_t* idx;             /* [M] */
+} c1v_vocab_argmax_noalloc_args;
+int c1v_vocab_argmax_noalloc(const c1v_vocab_argmax_noalloc_args*, void* stream);
 /* merge per-shard results gathered from R ranks: ties -> lowest global index */
 int c1v_argmax_merge(const float* scores /*[R][M]*/, const int32_t* idxs, int32_t R, int32_t M, float* score, int32_t* idx, void* stream);
 

@@ -37,7 +37,10 @@ CASES = {
     'k4': dict(B=2, T_in=15, T_out=14, E=5, n_filters=(4, 6), k=4, D=3, N=11),
     'k2': dict(B=5, T_in=9, T_out=9, E=40, n_filters=(33,), k=2, D=3, N=130),
     'mid': dict(B=16, T_in=20, T_out=18, E=62, n_filters=(48, 40), k=3, D=24, N=300),
-    'wide': dict(B=8, T_in=16, T_out=16, E=100, n_filters=(32,), k=3, D=16, N=500),   # kp=128: unfused loss path in bf16
+    'wide': dict(B=8, T_in=16, T_out=16, E=100, n_filters=(32,), k=3, D=16, N=500),   # kp=128 (100-d embeddings)
+    'kp192': dict(B=6, T_in=14, T_out=13, E=150, n_filters=(24,), k=3, D=12, N=400),
+    'kp256': dict(B=6, T_in=14, T_out=15, E=200, n_filters=(24,), k=3, D=12, N=700),  # 200-d embeddings
+    'kp384': dict(B=4, T_in=12, T_out=12, E=340, n_filters=(16,), k=3, D=8, N=300),   # wider than any fused kernel: unfused path
     'big128': dict(B=2048, T_in=32, T_out=32, E=62, n_filters=(128,), k=3, D=32, N=200),   # 128x128 GEMM tiles (>= 384 of them)
     'longflat': dict(B=8, T_in=70, T_out=20, E=30, n_filters=(64,), k=3, D=16, N=90),   # flat = 2176: split-K heads GEMM (8 slabs)
 }
@@ -84,6 +87,8 @@ def test_train_forward_backward_parity(name, dtype):
     eng = build_engine(c, og, params, Wv, dtype)
     if name == 'longflat':
         assert eng.heads_splits == 8
+    if dtype == 'bf16':
+        assert (eng.logits is None) == (name != 'kp384'), 'fused stream kernel expected for every width up to 320'
     load_fixed(eng, x, ids, eps, mask_e, mask_d)
     eng._run(eng.train_ops(False))
     torch.cuda.synchronize()
@@ -278,6 +283,24 @@ def test_eval_loss_all_rows_with_256_row_workgroups(monkeypatch):
     load_fixed(eng, x, ids, eps, mask_e, mask_d)
     eng.eval_step(use_graph=False, fixed_rng=True)
     assert abs(eng.loss() - ref) < 1e-2 * max(1.0, abs(ref))
+
+
+def test_decode_latent_right_after_a_train_step_uses_the_updated_weights():
+    """The graph-replayed train step leaves the refresh of the weights' operand copies to the NEXT step's prologue;
+    vae_decoder_.predict_on_batch called in between must not run on copies that are one optimizer step old."""
+    c = CASES['mid']
+    og, params, Wv, x, ids, eps, mask_e, mask_d = make_case(c, seed=8)
+    eng = build_engine(c, og, params, Wv, 'f32')
+    load_fixed(eng, x, ids, eps, mask_e, mask_d)
+    for _ in range(2):
+        eng.train_step(use_graph=True, fixed_rng=True)
+    z = np.random.RandomState(1).standard_normal((c['B'], c['D'])).astype(np.float32)
+    y = eng.decode_latent(torch.from_numpy(z).to(eng.dev)).cpu().numpy()
+    w_now = {k: v.astype(np.float64) for k, v in eng.get_weights().items()}
+    ref = O.decoder_forward(og, w_now, z.astype(np.float64))
+    assert rel_err(y, ref) < 1e-4
+    old = O.decoder_forward(og, {k: v.astype(np.float64) for k, v in params.items()}, z.astype(np.float64))
+    assert rel_err(old, ref) > 1e-3                    # the step did move the decoder: stale copies would have shown
 
 
 def test_frozen_encoder_keeps_encoder_weights():

@@ -78,11 +78,16 @@ def test_fit_positive01(text_vae, corpus):
 def test_fit_positive03_warm_start_keeps_encoder(text_vae, corpus):
     res = text_vae.fit(corpus[0])
     enc_before = res.vae_encoder_.get_weights()
+    # `vae_encoder_` is Model(encoder_input, z_mean) (:1308): the z_log_var head is not part of it ...
+    assert not any(k.startswith('z_log_var') for k in enc_before) and any(k.startswith('z_mean') for k in enc_before)
+    lv_before = res._vae_runtime.weights()['z_log_var/kernel'].copy()
     res.warm_start = True
     res.fit(corpus[0], corpus[1])
     _assert_fitted(res)
     enc_after = res.vae_encoder_.get_weights()
     assert set(enc_before) == set(enc_after)
+    # ... so a warm start gives that head a fresh initialisation (and freezes it with the rest of the encoder, :1245)
+    assert not np.array_equal(lv_before, res._vae_runtime.weights()['z_log_var/kernel'])
     for k in enc_before:                                   # encoder layers are frozen in a warm start (:1228, :1244-1245)
         np.testing.assert_array_equal(enc_before[k], enc_after[k])
 

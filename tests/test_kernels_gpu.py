@@ -24,7 +24,9 @@ def _stream():
 
 # ------------------------------------------------------------------------------------------------ a10-ii
 @pytest.mark.parametrize('dtype,K,N,M', [('bf16', 300, 5000, 700), ('bf16', 302, 333, 129), ('bf16', 30, 1000, 64),
-                                         ('bf16', 60, 130, 10), ('f32', 300, 3000, 200), ('bf16', 100, 900, 77)])
+                                         ('bf16', 60, 130, 10), ('f32', 300, 3000, 200), ('bf16', 100, 900, 77),
+                                         ('bf16', 150, 1100, 130), ('bf16', 200, 2100, 260), ('bf16', 256, 700, 33),
+                                         ('bf16', 340, 600, 50)])
 def test_vocab_argmax_matches_oracle(dtype, K, N, M):
     L, engine, _, _ = _mods()
     rng = np.random.RandomState(K + N)
