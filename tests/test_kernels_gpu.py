@@ -150,22 +150,92 @@ def test_c2_full_size_step_matches_oracle(dtype):
     eng.keep_d.copy_(torch.from_numpy(md.astype(np.uint8)))
     eng._run(eng.train_ops(False))
     torch.cuda.synchronize()
-    tol = 2e-4 if dtype == 'f32' else 2e-2
-    y = eng.y_pred().cpu().numpy()
-    assert np.abs(y - acts['y_pred']).max() / np.abs(acts['y_pred']).max() < tol
+    from parity import assert_activation, engine_decisions, rel_l2
+    if dtype == 'f32':
+        # (the oracle itself runs in float32 here: 2e-4 instead of the 1e-4 the float64-oracle tests hold the kernels to)
+        y = eng.y_pred().cpu().numpy()
+        assert np.abs(y - acts['y_pred']).max() / np.abs(acts['y_pred']).max() < 2e-4
+    else:
+        mlv = eng.mlv.cpu().numpy()
+        for k_, got in (('z_mean', mlv[:, :D]), ('z_log_var', mlv[:, D:]), ('z', eng.z_out.cpu().numpy()),
+                        ('y_pred', eng.y_pred().cpu().numpy())):
+            r, e = assert_activation(got, acts[k_], dtype, k_)
+            print('C2 bf16', k_, 'worst row rel-L2 %.3e  max-rel %.3e' % (r, e))
     assert abs(eng.loss() - loss) < (2e-4 if dtype == 'f32' else 1e-2) * abs(loss)
     gg = eng.get_grads()
+    if dtype == 'bf16':
+        # the oracle's backward pass on the ReLU / max-pool choices the bf16 run made
+        _, same_choice, _ = O.train_forward_backward(og, params, W, x, ids, eps, me, md, decisions=engine_decisions(eng))
     for k_, ref in grads.items():
-        err = np.linalg.norm(gg[k_].astype(np.float64) - ref) / max(np.linalg.norm(ref), 1e-30)
-        # bf16: the error is dominated by ReLU / max-pool decisions that flip where a pre-activation is within bf16
-        # rounding of zero or of its pool partner: a fraction f of wrong elements costs sqrt(f) in the Frobenius norm
-        # (measured 0.2 % after the loss, 1.7 % after one ReLU layer, 5-7 % at the encoder), inherent to bf16 storage
-        assert err < (1e-3 if dtype == 'f32' else 0.12), (k_, err)
+        err = rel_l2(gg[k_], ref)
+        if dtype == 'f32':
+            assert err < 1e-3, (k_, err)
+            continue
+        # bf16, measured exception: a bf16 forward pass flips the ReLU / max-pool choice of the ~0.3 % of elements that are
+        # within its rounding of a tie; a fraction f of flipped choices costs sqrt(f) of a gradient's Frobenius norm per
+        # layer crossed (0.2 % after the loss, ~2 % after one ReLU layer, 5-7 % at the encoder).  With the choices held
+        # equal the gradients agree to the activation tolerance.
+        errs = rel_l2(gg[k_], same_choice[k_])
+        print('C2 bf16 grad', k_, 'rel-L2 %.3e (same ReLU / pool choices: %.3e)' % (err, errs))
+        assert err < 0.12, (k_, err)
+        assert errs < 1e-2, (k_, errs)
     losses = []
     for _ in range(4):
         eng.train_step(use_graph=True, fixed_rng=True)
         losses.append(eng.loss())
     assert np.all(np.isfinite(losses)) and losses[-1] < losses[0]
+
+
+def test_c2_size_loss_curve_100_steps_bf16_vs_f32_within_one_percent():
+    """north_star: loss curves within 1 % over 100 steps with fixed eps -- at the full C2 size (batch 256, seq_len 32,
+    emb 300, latent 256, vocabulary 8192).  The oracle affords three steps at this size, so the fp32 HIP path is pinned to
+    it there (float32 oracle) and the bf16 path is then held to the fp32 path over all 100 steps: same weights, the same
+    eight batches cycled, the same eps and dropout masks."""
+    L, engine, geometry, synthetic = _mods()
+    B, T, E, D, N = 256, 32, 300, 256, 8192
+    V = E + 2
+    W = synthetic.synthetic_vocab(N - 2, E)
+    og = O.VAEGeometry(T, T, V, V, (128,), 3, D)
+    params = O.init_params(og, seed=0)
+    rng = np.random.RandomState(7)
+    batches = []
+    for i in range(8):
+        x, ids = synthetic.synthetic_batch(W, N, B, T, T, seed=100 + i)
+        batches.append((x, ids, rng.standard_normal((B, D)).astype(np.float32),
+                        rng.uniform(size=(B, og.flat_size)) < 0.7, rng.uniform(size=(B, D)) < 0.7))
+    ref_p = {k: v.copy() for k, v in params.items()}
+    st = O.NadamState()
+    ref = []
+    for step in range(3):
+        x, ids, eps, me, md = batches[step % 8]
+        loss, grads, _ = O.train_forward_backward(og, ref_p, W, x, ids, eps, me, md)
+        O.nadam_step(ref_p, grads, st)
+        ref.append(loss)
+    g = geometry.Geometry(T, T, V, V, (128,), 3, D)
+    curves = {}
+    for dtype in ('f32', 'bf16'):
+        eng = engine.VAEEngine(g, B, W, dtype=dtype, weights=params)
+        dev_batches = [(torch.from_numpy(x).to(eng.dev), torch.from_numpy(ids).to(eng.dev), torch.from_numpy(eps).to(eng.dev),
+                        torch.from_numpy(me.astype(np.uint8)).to(eng.dev), torch.from_numpy(md.astype(np.uint8)).to(eng.dev))
+                       for x, ids, eps, me, md in batches]
+        got = []
+        for step in range(100):
+            x, ids, eps, me, md = dev_batches[step % 8]
+            eng.x_in.copy_(x)
+            eng.ids_in.copy_(ids)
+            eng.eps.copy_(eps)
+            eng.keep_e.copy_(me)
+            eng.keep_d.copy_(md)
+            eng.train_step(use_graph=True, fixed_rng=True)
+            got.append(eng.loss())
+        curves[dtype] = np.array(got)
+        del eng
+    np.testing.assert_allclose(curves['f32'][:3], ref, rtol=1e-3)
+    assert curves['f32'][-1] < 0.97 * curves['f32'][0]              # it trains
+    dev = np.max(np.abs(curves['bf16'] - curves['f32']) / curves['f32'])
+    print('C2 size: max relative deviation of the bf16 loss curve from the fp32 one over 100 steps: %.3e (loss %.3f -> %.3f)'
+          % (dev, curves['f32'][0], curves['f32'][-1]))
+    assert dev < 1e-2
 
 
 def test_loss_curve_100_steps_within_one_percent():
