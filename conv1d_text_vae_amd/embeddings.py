@@ -197,3 +197,99 @@ def load_word2vec_text(path: str, limit: Optional[int] = None) -> FastTextKeyedV
     kv = FastTextKeyedVectors(dim, 0, 0, 0)
     kv.add(words, np.vstack(rows) if rows else np.zeros((0, dim), dtype=np.float32))
     return kv
+
+
+FASTTEXT_MAGIC = 793712314          # FASTTEXT_FILEFORMAT_MAGIC_INT32 of the facebookresearch/fastText binary format
+FASTTEXT_VERSION = 12
+
+
+def load_fasttext_bin(path: str, limit: Optional[int] = None) -> FastTextKeyedVectors:
+    """Reader for a native FastText `.bin` model (`cc.ru.300.bin`, `cc.en.300.bin`, ...; a `.gz` of one is opened in
+    place) given a LOCAL path.  The reference obtains the same object by downloading such a file and handing it to gensim
+    (fasttext_loading.py:27, :43, :59); gensim and the network are absent here, so the published layout of the file is
+    read directly:
+
+        int32 magic, int32 version
+        args:  12 x int32 (dim, ws, epoch, minCount, neg, wordNgrams, loss, model, bucket, minn, maxn, lrUpdateRate), double t
+        dictionary:  int32 size, int32 nwords, int32 nlabels, int64 ntokens, int64 pruneidx_size,
+                     size x (zero-terminated UTF-8 word, int64 count, int8 type), pruneidx_size x (int32, int32)
+        input matrix:  bool quantised, int64 rows (= nwords + bucket), int64 dim, rows x dim float32
+        (output matrix: not needed for word vectors, not read)
+
+    Vectors follow gensim's `FastTextKeyedVectors`: an in-vocabulary word is the mean of its own input row and the rows of
+    its character n-grams (hashed into `bucket` rows behind the words); an out-of-vocabulary word is the mean of its
+    n-gram rows.  `limit` keeps only the first words of the dictionary (they are sorted by frequency).  Quantised
+    (`.ftz`) models and pruned dictionaries are refused."""
+    import gzip
+    import struct
+    if not os.path.isfile(path):
+        raise FileNotFoundError(path)
+    opener = gzip.open if path.endswith('.gz') else open
+    with opener(path, 'rb') as fp:
+        def take(fmt):
+            size = struct.calcsize(fmt)
+            raw = fp.read(size)
+            if len(raw) != size:
+                raise ValueError('`{0}` is not a FastText model: the file ends inside its header.'.format(path))
+            return struct.unpack(fmt, raw)
+        magic, version = take('<ii')
+        if magic != FASTTEXT_MAGIC:
+            raise ValueError('`{0}` is not a FastText model (magic number {1}).'.format(path, magic))
+        if version > FASTTEXT_VERSION:
+            raise ValueError('`{0}`: unsupported FastText format version {1}.'.format(path, version))
+        dim, _ws, _epoch, _min_count, _neg, _word_ngrams, _loss, _model, bucket, minn, maxn, _lr_update = take('<12i')
+        take('<d')
+        size, nwords, _nlabels = take('<3i')
+        _ntokens, pruneidx_size = take('<qq')
+        if pruneidx_size > 0:
+            raise ValueError('`{0}`: pruned (quantised) FastText dictionaries are not supported.'.format(path))
+        words: List[str] = []
+        for _ in range(size):
+            chunk = bytearray()
+            while True:
+                ch = fp.read(1)
+                if not ch:
+                    raise ValueError('`{0}`: the dictionary is truncated.'.format(path))
+                if ch == b'\x00':
+                    break
+                chunk += ch
+            _count, kind = take('<qb')
+            if kind == 0:                                   # 0 = word, 1 = label of a supervised model
+                words.append(chunk.decode('utf-8', errors='ignore'))
+        if len(words) != nwords:
+            raise ValueError('`{0}`: the dictionary holds {1} words, its header says {2}.'.format(path, len(words), nwords))
+        quantised, = take('<?')
+        if quantised:
+            raise ValueError('`{0}`: quantised FastText models are not supported.'.format(path))
+        rows, cols = take('<qq')
+        if cols != dim or rows != nwords + bucket:
+            raise ValueError('`{0}`: the input matrix is {1} x {2}, expected {3} x {4}.'.format(
+                path, rows, cols, nwords + bucket, dim))
+
+        def read_rows(n):
+            want = n * dim * 4
+            raw = fp.read(want)
+            if len(raw) != want:
+                raise ValueError('`{0}`: the input matrix is truncated.'.format(path))
+            return np.frombuffer(raw, dtype='<f4').reshape(n, dim).astype(np.float32)
+        keep = nwords if limit is None else max(0, min(int(limit), nwords))
+        vocab_rows = read_rows(keep)
+        if keep < nwords:                                    # skip the rows of the words beyond `limit`
+            skip = (nwords - keep) * dim * 4
+            while skip > 0:
+                got = fp.read(min(skip, 1 << 24))
+                if not got:
+                    raise ValueError('`{0}`: the input matrix is truncated.'.format(path))
+                skip -= len(got)
+        ngram_rows = read_rows(bucket)
+    kv = FastTextKeyedVectors(dim, minn, maxn, bucket)
+    kv.vectors_ngrams = ngram_rows
+    final = np.empty_like(vocab_rows)
+    for i, w in enumerate(words[:keep]):
+        ngrams = compute_ngrams(w, minn, maxn) if bucket > 0 else []
+        acc = vocab_rows[i].astype(np.float32).copy()
+        if ngrams:
+            acc += ngram_rows[[ft_hash(g) % bucket for g in ngrams]].sum(axis=0)
+        final[i] = acc / np.float32(len(ngrams) + 1)
+    kv.add(words[:keep], final)
+    return kv

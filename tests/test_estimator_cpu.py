@@ -508,3 +508,80 @@ def test_run_epochs_shuffles_batches_and_restores_best():
     assert state['lr'] < 0.002
     with pytest.raises(ValueError):
         training.run_epochs(0, 1, 1, train_batch, train_batch, epoch_losses, None, None, None, None)
+
+
+# ---- FastText .bin reader (reference fasttext_loading.py:27, :43, :59) ---------------------------------
+def _write_fasttext_bin(path, words, dim, minn, maxn, bucket, rng, labels=()):
+    """A tiny native FastText model written field by field (the published layout of the format)."""
+    import struct
+    entries = [(w, 0) for w in words] + [(lb, 1) for lb in labels]
+    mat = rng.standard_normal((len(words) + bucket, dim)).astype('<f4')
+    with open(path, 'wb') as fp:
+        fp.write(struct.pack('<ii', 793712314, 12))
+        fp.write(struct.pack('<12i', dim, 5, 5, 1, 5, 1, 1, 2, bucket, minn, maxn, 100))
+        fp.write(struct.pack('<d', 1e-4))
+        fp.write(struct.pack('<3i', len(entries), len(words), len(labels)))
+        fp.write(struct.pack('<qq', 12345, -1))
+        for i, (w, kind) in enumerate(entries):
+            fp.write(w.encode('utf-8') + b'\x00')
+            fp.write(struct.pack('<qb', 100 - i, kind))
+        fp.write(struct.pack('<?', False))
+        fp.write(struct.pack('<qq', mat.shape[0], dim))
+        fp.write(mat.tobytes())
+        fp.write(struct.pack('<?', False))                   # output matrix: present in real files, never read
+        fp.write(struct.pack('<qq', len(words), dim))
+        fp.write(np.zeros((len(words), dim), dtype='<f4').tobytes())
+    return mat
+
+
+def test_fasttext_bin_reader_round_trip(tmp_path):
+    from conv1d_text_vae_amd import embeddings as E
+    rng = np.random.RandomState(0)
+    words = ['мама', 'мыла', 'раму', 'the', 'cat', '</s>']
+    dim, minn, maxn, bucket = 12, 3, 5, 50
+    path = str(tmp_path / 'tiny.bin')
+    mat = _write_fasttext_bin(path, words, dim, minn, maxn, bucket, rng, labels=('__label__x',))
+    kv = E.load_fasttext_bin(path)
+    assert isinstance(kv, E.KEYED_VECTOR_TYPES) and kv.vector_size == dim and kv.index2word == words
+    assert (kv.min_n, kv.max_n, kv.bucket) == (minn, maxn, bucket)
+    np.testing.assert_array_equal(kv.vectors_ngrams, mat[len(words):])
+    for i, w in enumerate(words):
+        grams = E.compute_ngrams(w, minn, maxn)
+        want = (mat[i] + sum(mat[len(words) + E.ft_hash(g) % bucket] for g in grams)) / (len(grams) + 1)
+        np.testing.assert_allclose(kv[w], want, rtol=1e-6, atol=1e-7)
+    # an out-of-vocabulary word: the mean of its n-gram rows (FastText's sub-word fallback)
+    grams = E.compute_ngrams('мамонт', minn, maxn)
+    want = sum(mat[len(words) + E.ft_hash(g) % bucket] for g in grams) / len(grams)
+    np.testing.assert_allclose(kv['мамонт'], want, rtol=1e-6, atol=1e-7)
+    # `limit` keeps the most frequent words and still reads the n-gram rows behind ALL words
+    kv2 = E.load_fasttext_bin(path, limit=2)
+    assert kv2.index2word == words[:2]
+    np.testing.assert_array_equal(kv2.vectors_ngrams, mat[len(words):])
+    np.testing.assert_allclose(kv2['мама'], kv['мама'])
+    # the estimator accepts the object as its embedding model
+    from conv1d_text_vae_amd import Conv1dTextVAE
+    assert Conv1dTextVAE.calc_vector_size(kv, None) == dim + 2
+    Conv1dTextVAE(input_embeddings=kv, output_embeddings=kv).check_embeddings()
+
+
+def test_fasttext_bin_reader_refuses_what_it_cannot_read(tmp_path):
+    from conv1d_text_vae_amd import embeddings as E
+    bad = tmp_path / 'bad.bin'
+    bad.write_bytes(b'\x01\x02\x03\x04' * 40)
+    with pytest.raises(ValueError, match='is not a FastText model'):
+        E.load_fasttext_bin(str(bad))
+    with pytest.raises(FileNotFoundError):
+        E.load_fasttext_bin(str(tmp_path / 'absent.bin'))
+    # a gzip of a model is opened in place
+    import gzip
+    rng = np.random.RandomState(1)
+    path = str(tmp_path / 'm.bin')
+    _write_fasttext_bin(path, ['a', 'b'], 4, 2, 3, 10, rng)
+    with open(path, 'rb') as src, gzip.open(path + '.gz', 'wb') as dst:
+        dst.write(src.read())
+    assert E.load_fasttext_bin(path + '.gz').index2word == ['a', 'b']
+    # truncated matrix
+    data = open(path, 'rb').read()
+    (tmp_path / 'cut.bin').write_bytes(data[:len(data) // 2])
+    with pytest.raises(ValueError, match='truncated|ends inside'):
+        E.load_fasttext_bin(str(tmp_path / 'cut.bin'))
