@@ -57,6 +57,7 @@ static int conv_params(const c1v_conv1d_args* a, const char* what, NtParams& p) 
     p.A = (const char*)a->x.data; p.a_bstride_b = a->x.bstride * es; p.lda_b = (int64_t)a->x.cp * es; p.a_off = a->a_off;
     p.W = (const char*)a->w_op; p.ldw_b = a->ldw * es; p.Kb = (int64_t)a->k * a->x.cp * es;
     C1V_REQUIRE(a->ldw >= (int64_t)a->k * a->x.cp, "%s: ldw (%lld) is smaller than k*cp", what, (long long)a->ldw);
+    if (a->k > 1 && ((int64_t)a->x.cp * es) % 128 == 0) { p.k_taps = a->k; p.k_strips = (int)((int64_t)a->x.cp * es / 128); }
     const int64_t M = (int64_t)a->x.batch * Le;
     C1V_REQUIRE(M < (1ll << 31), "%s: too many rows", what);
     return c1v_fill_epi(a->epi, p.e, (int)M, Le, a->n_rows, a->n_out);

@@ -116,6 +116,11 @@ struct NtParams {
     const char* W; int64_t ldw_b;
     int64_t Kb;                                                      // K in bytes
     int ksplits, kt_per_split; int64_t dst_split_stride;             // split-K (grid z): K tiles [s*kt_per_split, ..) -> dst + s*stride
+    // Order of the K tiles of a convolution (k_taps > 1): K = taps x (k_strips 128-byte column strips of a buffer row).  Tile
+    // t covers strip t / k_taps of tap t % k_taps, i.e. byte offset (t % k_taps) * k_strips * 128 + (t / k_taps) * 128 of
+    // both operands' rows: the taps of one strip are consecutive tiles, and tap j + 1 re-reads the lines tap j has just
+    // fetched (the same buffer rows, shifted by one) while they are still in the XCD's L2.  k_taps <= 1: natural order.
+    int k_taps, k_strips;
     EpiDev e;
 };
 

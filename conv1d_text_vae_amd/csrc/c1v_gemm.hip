@@ -8,6 +8,12 @@ __global__ __launch_bounds__(C1V_GEMM_THREADS) void gemm_nt_kernel(const NtParam
     c1v_touch_kernarg<4>();
     nt_body<T, BM, BN, NS>(p, blockIdx.x, blockIdx.y, blockIdx.x + gridDim.x * blockIdx.y, blockIdx.z);
 }
+// large-GEMM variant: two workgroups per CU (12 waves = 3 per SIMD)
+template <typename T, int NS>
+__global__ __launch_bounds__(C1V_GEMM_THREADS, 3) void gemm_nt_large_kernel(const NtParams p) {
+    c1v_touch_kernarg<4>();
+    nt_body<T, 128, 128, NS, false>(p, blockIdx.x, blockIdx.y, blockIdx.x + gridDim.x * blockIdx.y, 0);
+}
 template <typename T>
 __global__ __launch_bounds__(C1V_GEMM_THREADS) void gemm_tn_kernel(const TnParams p) {
     tn_body<T>(p, blockIdx.x, blockIdx.y, blockIdx.z);
@@ -17,14 +23,30 @@ __global__ __launch_bounds__(C1V_GEMM_THREADS) void gemm_tn_kernel(const TnParam
 // host launchers
 // ------------------------------------------------------------------------------------------------------
 template <typename T, int BM, int BN, int NS> static void launch_nt_v(const NtParams& p, hipStream_t st) {
-    constexpr int LDS = NS * (BM + BN) * 128;
+    constexpr int LDS = nt_lds<BM, BN, NS>();
     static bool once = (set_lds(gemm_nt_kernel<T, BM, BN, NS>, LDS), true); (void)once;
     dim3 grid((unsigned)c1v_cdiv(p.e.M, BM), (unsigned)c1v_cdiv(p.e.N, BN), (unsigned)(p.ksplits > 1 ? p.ksplits : 1));
     hipLaunchKernelGGL((gemm_nt_kernel<T, BM, BN, NS>), grid, dim3(C1V_GEMM_THREADS), LDS, st, p);
 }
 
+template <typename T, int NS> static void launch_nt_large_ns(const NtParams& p, hipStream_t st) {
+    constexpr int LDS = nt_lds<128, 128, NS>();
+    static bool once = (set_lds(gemm_nt_large_kernel<T, NS>, LDS), true); (void)once;
+    // M tiles fastest: the workgroups that run together share the weight tile and stream the activations
+    dim3 grid((unsigned)c1v_cdiv(p.e.M, 128), (unsigned)c1v_cdiv(p.e.N, 128), 1);
+    hipLaunchKernelGGL((gemm_nt_large_kernel<T, NS>), grid, dim3(C1V_GEMM_THREADS), LDS, st, p);
+}
+template <typename T> static void launch_nt_large(const NtParams& p, hipStream_t st) {
+    switch (nt_large_ns()) {
+        case 4:  launch_nt_large_ns<T, 4>(p, st); break;
+        case 5:  launch_nt_large_ns<T, 5>(p, st); break;
+        default: launch_nt_large_ns<T, 2>(p, st); break;
+    }
+}
+
 template <typename T> static int launch_nt_t(const NtParams& p, hipStream_t st) {
     switch (nt_variant(p)) {
+        case NT_128L:    launch_nt_large<T>(p, st); break;
         case NT_128:     launch_nt_v<T, 128, 128, 3>(p, st); break;
         default:         launch_nt_v<T, 64, 64, 4>(p, st); break;
     }

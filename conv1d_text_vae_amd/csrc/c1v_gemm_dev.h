@@ -19,6 +19,7 @@
 // tails rely on zero padding of the operand buffers (documented in include/c1dvae.h).
 #pragma once
 #include "c1v_common.h"
+#include <stdlib.h>
 
 // ------------------------------------------------------------------------------------------------------
 // fragment MMA: 16 bytes of K per lane
@@ -440,6 +441,22 @@ __device__ __forceinline__ void epi_fast_rows(const EpiDev& e, const RowDiv& rd,
     }
 }
 
+// the same rows with ONE state: every chunk is requested, then finished (large-GEMM variant: a second workgroup on the CU
+// hides the latency, and two states in flight would not fit its register budget)
+template <int BM, int BN, int MODE, int VW>
+__device__ __forceinline__ void epi_seq_rows(const EpiDev& e, const RowDiv& rd, const float* ct, int LDC, int m0, int n0, int tid,
+                                             const float bias4[4]) {
+    using S = EpiShape<BM, BN, MODE>;
+    if constexpr (MODE != C1V_ROW_LATENT_BWD) {          // (the latent head's dgrad is a small GEMM: never this variant)
+        EpiState s;
+#pragma unroll 1
+        for (int j0 = 0; j0 < S::ITEMS; j0 += S::CH) {
+            epi_load<BM, BN, MODE, VW>(e, rd, s, m0, n0, tid, j0);
+            epi_finish<BM, BN, MODE, VW>(e, s, ct, LDC, tid, j0, bias4);
+        }
+    }
+}
+
 // wave-uniform dispatch over the row mode at a fixed vector width
 #define C1V_EPI_DISPATCH(VWV, CALL)                                                      \
     switch (p.e.row_mode) {                                                              \
@@ -473,7 +490,11 @@ extern "C" int c1v_debug_read_nt(unsigned long long* dst, int n) {
 // with its ~170 cycles of fragment reads and ~200 of MFMA -- 580 cycles per tile against 256 for the data alone.
 constexpr int C1V_GEMM_THREADS = 384;
 
-template <typename T, int BM, int BN, int NS>
+// PRE: the epilogue inputs of the first chunk of rows are requested before the K loop (small GEMMs: their latency hides
+// behind it).  The large-GEMM variant (PRE = false) asks for them after the K loop instead: they would pin ~66 registers
+// through it, and that variant runs TWO workgroups per CU (<= 168 registers), where the other workgroup's K loop hides
+// this one's epilogue.
+template <typename T, int BM, int BN, int NS, bool PRE = true>
 __device__ __forceinline__ void nt_body(const NtParams& p, const int bx, const int by, const int wg_linear, const int ks = 0) {
 #ifdef NT_STAMP
     unsigned long long stamp[16];
@@ -521,11 +542,17 @@ __device__ __forceinline__ void nt_body(const NtParams& p, const int bx, const i
             }
         }
         const int dst0 = wave == 4 ? 0 : BM * 128;
+        // byte offset of the next K tile in both operands' rows (tiles are issued strictly in order): NtParams::k_taps
+        int tap_i = 0;
+        int64_t ko = (int64_t)kt0 * 128;
+        const int64_t tap_b = (int64_t)p.k_strips * 128;
         auto issue = [&](int kt) {
             char* d = smem + (kt % NS) * STAGE + dst0;
-            const int64_t ko = (int64_t)(kt0 + kt) * 128;
 #pragma unroll
             for (int i = 0; i < IPT; ++i) glds16(src[i] + ko, d + i * 1024);
+            if (p.k_taps > 1) {
+                if (++tap_i == p.k_taps) { tap_i = 0; ko += 128 - (int64_t)(p.k_taps - 1) * tap_b; } else ko += tap_b;
+            } else ko += 128;
         };
 #pragma unroll
         for (int s = 0; s < NS - 1; ++s)
@@ -576,8 +603,10 @@ __device__ __forceinline__ void nt_body(const NtParams& p, const int bx, const i
         }
     }
     // epilogue inputs of the first chunk of rows: requested while the feeders fill the ring
-    if (fastw == 4) { C1V_EPI_DISPATCH(4, (epi_load<BM, BN, MODE_, VW_>(ev, rd, es, m0, n0, tid, 0))) }
-    else if (fastw == 2) { C1V_EPI_DISPATCH(2, (epi_load<BM, BN, MODE_, VW_>(ev, rd, es, m0, n0, tid, 0))) }
+    if constexpr (PRE) {
+        if (fastw == 4) { C1V_EPI_DISPATCH(4, (epi_load<BM, BN, MODE_, VW_>(ev, rd, es, m0, n0, tid, 0))) }
+        else if (fastw == 2) { C1V_EPI_DISPATCH(2, (epi_load<BM, BN, MODE_, VW_>(ev, rd, es, m0, n0, tid, 0))) }
+    }
     NT_T(1);
 
     for (int kt = 0; kt < KT; ++kt) {
@@ -619,9 +648,13 @@ __device__ __forceinline__ void nt_body(const NtParams& p, const int bx, const i
                 ct[(wm * WTM + i * 16 + (lane >> 4) * 4 + r) * LDC + wn * WTN + j * 16 + (lane & 15)] = acc[i][j][r];
     __syncthreads();
     NT_T(5);
-    if (fastw == 4) { C1V_EPI_DISPATCH(4, (epi_fast_rows<BM, BN, MODE_, VW_>(ev, rd, es, ct, LDC, m0, n0, tid, bias4))) }
+    if constexpr (!PRE) {
+        if (fastw == 4) { C1V_EPI_DISPATCH(4, (epi_seq_rows<BM, BN, MODE_, VW_>(ev, rd, ct, LDC, m0, n0, tid, bias4))) }
+        else if (fastw == 2) { C1V_EPI_DISPATCH(2, (epi_seq_rows<BM, BN, MODE_, VW_>(ev, rd, ct, LDC, m0, n0, tid, bias4))) }
+    } else if (fastw == 4) { C1V_EPI_DISPATCH(4, (epi_fast_rows<BM, BN, MODE_, VW_>(ev, rd, es, ct, LDC, m0, n0, tid, bias4))) }
     else if (fastw == 2) { C1V_EPI_DISPATCH(2, (epi_fast_rows<BM, BN, MODE_, VW_>(ev, rd, es, ct, LDC, m0, n0, tid, bias4))) }
-    else {
+    if (fastw != 0) {
+    } else {
         switch (ev.row_mode) {                        // wave-uniform; one specialised epilogue each
             case C1V_ROW_STORE:   epilogue_rows<BM, BN, C1V_ROW_STORE>(ev, ct, LDC, m0, n0, tid, bias4); break;
             case C1V_ROW_POOL2:   epilogue_rows<BM, BN, C1V_ROW_POOL2>(ev, ct, LDC, m0, n0, tid, bias4); break;
@@ -805,12 +838,32 @@ __device__ __forceinline__ void tn_body(const TnParams& p, const int bx, const i
 
 // LDS needs and tile choice, shared by the launchers of c1v_gemm.hip and c1v_gemm_pair.hip
 constexpr int TN_LDS = TN_NS * 2 * TN_TILE;
-enum NtVariant { NT_128 = 0, NT_64 = 2 };
+enum NtVariant { NT_128 = 0, NT_128L = 1, NT_64 = 2 };
+// LDS of an NT workgroup: the operand ring, reused by the epilogue for the parked fp32 tile (BM x (BN + 4))
+template <int BM, int BN, int NS> constexpr int nt_lds() {
+    return NS * (BM + BN) * 128 > BM * (BN + 4) * 4 ? NS * (BM + BN) * 128 : BM * (BN + 4) * 4;
+}
+static inline int64_t nt_large_tiles() {
+    // (diagnostic / test override: the tile count from which the large-GEMM variant is taken)
+    const char* env = getenv("C1V_NT_LARGE_TILES");
+    return env ? atoll(env) : 768;
+}
+static inline int nt_large_ns() {
+    // ring depth of the large-GEMM variant: 2 stages = 64 KiB = two workgroups per CU; 4 / 5 stages = one workgroup per CU
+    // with 3 / 4 tiles in flight (diagnostic override)
+    const char* env = getenv("C1V_NT_LARGE_NS");
+    return env ? atoi(env) : 2;
+}
 static inline NtVariant nt_variant(const NtParams& p) {
     // Measured (s_memtime stamps, compute removed): a CU takes in ~30 B/clk whatever the depth of the ring, so the K loops
     // of these small GEMMs are bound by the bytes ONE workgroup needs; shallow rings that let two workgroups share a CU
     // (and a wgrad + dgrad pair share the chip) beat deep ones.
+    // Large GEMMs (several rounds of 128 x 128 tiles on every CU; the C4 stack at batch 2048): NT_128L = the same tile with
+    // a two-stage ring (64 KiB) and <= 168 registers, so that TWO workgroups share a CU and one's epilogue (as long as its
+    // K loop at these K) runs under the other's K loop.  Split-K launches and the latent head's dgrad (M = batch: always
+    // small) keep the small-GEMM variants.
     const int64_t tiles128 = c1v_cdiv(p.e.M, 128) * c1v_cdiv(p.e.N, 128);
+    if (p.ksplits <= 1 && p.e.row_mode != C1V_ROW_LATENT_BWD && tiles128 >= nt_large_tiles()) return NT_128L;
     return tiles128 >= 384 ? NT_128 : NT_64;
 }
 template <typename K> static void set_lds(K kern, int bytes) {

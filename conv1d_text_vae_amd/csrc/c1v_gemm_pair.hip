@@ -27,8 +27,40 @@ __global__ __launch_bounds__(C1V_GEMM_THREADS) void gemm_pair_kernel(const PairP
     }
 }
 
+// large-GEMM variant (see nt_variant): two workgroups per CU
+template <typename T, int NS>
+__global__ __launch_bounds__(C1V_GEMM_THREADS, 3) void gemm_pair_large_kernel(const PairParams pp) {
+    c1v_touch_kernarg<7>();
+    const int id = blockIdx.x;
+    if (id < pp.tn_blocks) {
+        const int bz = id / pp.tn_gij, r = id - bz * pp.tn_gij;
+        const int by = r / pp.tn_gi, bx = r - by * pp.tn_gi;
+        tn_body<T>(pp.tn, bx, by, bz);
+    } else {
+        const int r = id - pp.tn_blocks;
+        const int by = r / pp.nt_gm, bx = r - by * pp.nt_gm;
+        nt_body<T, 128, 128, NS, false>(pp.nt, bx, by, r);
+    }
+}
+
+template <typename T, int NS> static void launch_pair_large_ns(PairParams& pp, hipStream_t st) {
+    constexpr int NT_LDS = nt_lds<128, 128, NS>();
+    constexpr int LDS = NT_LDS > TN_LDS ? NT_LDS : TN_LDS;
+    static bool once = (set_lds(gemm_pair_large_kernel<T, NS>, LDS), true); (void)once;
+    pp.nt_gm = (int)c1v_cdiv(pp.nt.e.M, 128);
+    const int64_t nt_blocks = (int64_t)pp.nt_gm * c1v_cdiv(pp.nt.e.N, 128);
+    hipLaunchKernelGGL((gemm_pair_large_kernel<T, NS>), dim3((unsigned)(pp.tn_blocks + nt_blocks)), dim3(C1V_GEMM_THREADS), LDS, st, pp);
+}
+template <typename T> static void launch_pair_large(PairParams& pp, hipStream_t st) {
+    switch (nt_large_ns()) {
+        case 4:  launch_pair_large_ns<T, 4>(pp, st); break;
+        case 5:  launch_pair_large_ns<T, 5>(pp, st); break;
+        default: launch_pair_large_ns<T, 2>(pp, st); break;
+    }
+}
+
 template <typename T, int BM, int BN, int NS> static void launch_pair_v(PairParams& pp, hipStream_t st) {
-    constexpr int NT_LDS = NS * (BM + BN) * 128;
+    constexpr int NT_LDS = nt_lds<BM, BN, NS>();
     constexpr int LDS = NT_LDS > TN_LDS ? NT_LDS : TN_LDS;
     static bool once = (set_lds(gemm_pair_kernel<T, BM, BN, NS>, LDS), true); (void)once;
     pp.nt_gm = (int)c1v_cdiv(pp.nt.e.M, BM);
@@ -38,6 +70,7 @@ template <typename T, int BM, int BN, int NS> static void launch_pair_v(PairPara
 
 template <typename T> static int launch_pair_t(PairParams& pp, hipStream_t st) {
     switch (nt_variant(pp.nt)) {
+        case NT_128L:    launch_pair_large<T>(pp, st); break;
         case NT_128:     launch_pair_v<T, 128, 128, 3>(pp, st); break;
         default:         launch_pair_v<T, 64, 64, 4>(pp, st); break;
     }

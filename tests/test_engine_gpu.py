@@ -104,6 +104,44 @@ def test_train_forward_backward_parity(name, dtype):
             assert rel_err(g[k_], ref) < 0.3, (k_, rel_err(g[k_], ref))
 
 
+@pytest.mark.parametrize('name', ['tiny1', 'deep3', 'k4', 'mid', 'kp192', 'big128'])
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_large_gemm_variant_parity(name, dtype, monkeypatch):
+    """The large-GEMM variant of the NT kernel (128 x 128 tile, two-stage ring, two workgroups per CU, epilogue inputs
+    requested after the K loop) is normally taken from 768 tiles on -- the C4 stack at batch 2048.  Forced here onto every
+    GEMM of the small cases (all epilogue modes, ragged tiles, odd channel counts): the same parity bars against the
+    oracle, and bit-identical results to the default variants (same MFMA order per output element)."""
+    c = CASES[name]
+    og, params, Wv, x, ids, eps, mask_e, mask_d = make_case(c)
+    p64 = {k: v.astype(np.float64) for k, v in params.items()}
+    loss, grads, acts = O.train_forward_backward(og, p64, Wv.astype(np.float64), x.astype(np.float64), ids,
+                                                 eps.astype(np.float64), mask_e, mask_d)
+    got = {}
+    for mode in ('1', None):
+        if mode is None:
+            monkeypatch.delenv('C1V_NT_LARGE_TILES', raising=False)
+        else:
+            monkeypatch.setenv('C1V_NT_LARGE_TILES', mode)
+        eng = build_engine(c, og, params, Wv, dtype)
+        load_fixed(eng, x, ids, eps, mask_e, mask_d)
+        eng._run(eng.train_ops(False))
+        torch.cuda.synchronize()
+        got[mode] = (eng.loss(), eng.y_pred().cpu().numpy(), eng.mlv.cpu().numpy(), eng.get_grads())
+    l, y, mlv, g = got['1']
+    assert_activation(y, acts['y_pred'], dtype, 'y_pred')
+    assert_activation(mlv[:, :c['D']], acts['z_mean'], dtype, 'z_mean')
+    assert abs(l - loss) < (1e-4 if dtype == 'f32' else 1e-2) * max(1.0, abs(loss))
+    for k_, ref in grads.items():
+        if dtype == 'f32':
+            assert rel_err(g[k_], ref) < 2e-4, (k_, rel_err(g[k_], ref))
+        else:
+            assert rel_l2(g[k_], ref) < 0.1, (k_, rel_l2(g[k_], ref))
+    l0, y0, mlv0, g0 = got[None]
+    assert l == l0 and np.array_equal(y, y0) and np.array_equal(mlv, mlv0)
+    for k_ in g0:
+        np.testing.assert_array_equal(g[k_], g0[k_], err_msg=k_)
+
+
 @pytest.mark.parametrize('name', ['deep3', 'mid'])
 @pytest.mark.parametrize('dtype', ['f32', 'bf16'])
 def test_paired_backward_launch_is_bit_identical(name, dtype, monkeypatch):
