@@ -90,6 +90,17 @@ class LatentArgs(C.Structure):
                 ('part_stride', C.c_int64)]
 
 
+BN_POOL2, BN_UP2 = 1, 2
+BN_BLOCKS = 128          # partial-sum blocks of c1v_bn_reduce
+
+
+class BnArgs(C.Structure):
+    _fields_ = [('x', Seq), ('mode', C.c_int32), ('grad', Seq), ('sel', C.c_void_p), ('sel_bstride', C.c_int64),
+                ('sel_cp', C.c_int32), ('keep', C.c_void_p), ('keep_scale', C.c_float), ('mean', C.c_void_p),
+                ('var', C.c_void_p), ('eps', C.c_float), ('gamma', C.c_void_p), ('beta', C.c_void_p), ('sums', C.c_void_p),
+                ('n_global', C.c_int64), ('dst', Seq), ('sel_out', C.c_void_p)]
+
+
 class L2NormArgs(C.Structure):
     _fields_ = [('y', C.c_void_p), ('M', C.c_int32), ('V', C.c_int32), ('ldy', C.c_int64), ('yhat', C.c_void_p),
                 ('dtype', C.c_int32), ('kp', C.c_int32), ('rnorm', C.c_void_p), ('qscale', C.c_float), ('pos', C.c_void_p)]
@@ -187,6 +198,11 @@ SYMBOLS = {
     'c1v_pack_weights': ([C.c_void_p, C.c_int32, C.c_int32, C.c_void_p], C.c_int),
     'c1v_pack_input': ([_P(PackInputArgs), C.c_void_p], C.c_int),
     'c1v_gather_input': ([_P(GatherInputArgs), C.c_void_p], C.c_int),
+    'c1v_bn_reduce': ([_P(BnArgs), C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_float, C.c_void_p], C.c_int),
+    'c1v_bn_stats': ([C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                      C.c_void_p], C.c_int),
+    'c1v_bn_apply_fwd': ([_P(BnArgs), C.c_void_p], C.c_int),
+    'c1v_bn_apply_bwd': ([_P(BnArgs), C.c_void_p], C.c_int),
     'c1v_latent_head_fwd': ([_P(LatentArgs), C.c_void_p], C.c_int),
     'c1v_latent_head_bwd': ([_P(LatentArgs), C.c_void_p], C.c_int),
     'c1v_l2norm_rows': ([_P(L2NormArgs), C.c_void_p], C.c_int),

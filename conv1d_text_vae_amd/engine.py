@@ -24,7 +24,7 @@ import numpy as np
 import torch
 
 from . import _lib as L
-from .geometry import Geometry, init_keras_weights, merge_heads, split_heads
+from .geometry import BN_EPS, BN_MOMENTUM, Geometry, init_keras_weights, merge_heads, split_heads
 
 KEEP_PROB = 0.7          # Dropout(0.3) :1243, :1254
 TAU = 0.1                # :1319
@@ -125,6 +125,14 @@ class VAEEngine:
         self.sched = z(8)
         self.norm_out = z(1)
         self.step_ctr = torch.zeros(1, dtype=torch.int64, device=self.dev)
+        # BatchNormalization state (use_batch_norm=True): per layer the moving averages (not trainable: outside the flat
+        # parameter buffer), the statistics of the current batch and the two sum vectors of the forward / backward reductions
+        self.bn: Dict[str, dict] = {}
+        for name, ch in geom.bn_layers():
+            self.bn[name] = dict(C=ch, moving_mean=z(ch), moving_var=torch.ones(ch, dtype=torch.float32, device=self.dev),
+                                 mean=z(ch), var=z(ch), sums_f=z(2 * ch), sums_b=z(2 * ch), slab=z(2 * ch),
+                                 partial=z(L.BN_BLOCKS * 2 * ch))
+        self._dp_all_reduce = None
         self.set_weights(weights if weights is not None else init_keras_weights(geom, seed))
 
         # ---------------- activation buffers
@@ -191,6 +199,21 @@ class VAEEngine:
         self.Xf = seqbuf(B, pitch, geom.pad_left, To, c_in)
         self.dOf = seqbuf(B, pitch, k - 1, To, self.V)
         self.Y = Buf(z(B * To * self.V + 64), B, To * self.V, 0, To, self.V, self.V)
+        # use_batch_norm: the normalisation needs the convolutions' own (post-ReLU, un-pooled / un-upsampled) outputs and the
+        # gradients w.r.t. the pooled / upsampled tensors as buffers of their own
+        self.Ae: List[Buf] = []
+        self.dPe: List[Buf] = []
+        self.Ad: List[Buf] = []
+        self.dUd: List[Buf] = []
+        if geom.use_batch_norm:
+            for l in range(nl):
+                Fl = geom.n_filters[l]
+                self.Ae.append(seqbuf(B, _even(geom.enc_in_len[l] + k - 1), k - 1, geom.enc_len_conv[l], Fl))
+                self.dPe.append(seqbuf(B, _even(geom.enc_len_pool[l]), 0, geom.enc_len_pool[l], Fl))
+            for i, f in enumerate(geom.dec_filters):
+                nxt = self.Xf if i == len(geom.dec_filters) - 1 else self.Xd[i + 1]
+                self.Ad.append(seqbuf(B, _even(geom.dec_in_len[i] + 3 * (k - 1)), k - 1, geom.dec_len_deconv[i], f))
+                self.dUd.append(seqbuf(B, nxt.pitch, nxt.off, nxt.len, f))
         self.post = z(B, To, self.V - 1)
         self.end_idx = torch.zeros(B, dtype=torch.int32, device=self.dev)
 
@@ -224,6 +247,10 @@ class VAEEngine:
                 raise ValueError('weight `{0}` has shape {1}, expected {2}'.format(n, a.shape, self.seg_shapes[n]))
             host[self.seg_off[n]:self.seg_off[n] + a.size] = a.reshape(-1)
         self.params.copy_(torch.from_numpy(host))
+        for name, st in self.bn.items():
+            for key, attr in (('/moving_mean', 'moving_mean'), ('/moving_variance', 'moving_var')):
+                if name + key in w:
+                    st[attr].copy_(torch.from_numpy(np.asarray(w[name + key], dtype=np.float32)))
         if hasattr(self, '_pack_all'):
             self._pack_all()
 
@@ -231,6 +258,9 @@ class VAEEngine:
         host = self.params.detach().cpu().numpy()
         w = {n: host[self.seg_off[n]:self.seg_off[n] + int(np.prod(self.seg_shapes[n]))].reshape(self.seg_shapes[n]).copy()
              for n in self.seg_names}
+        for name, st in self.bn.items():
+            w[name + '/moving_mean'] = st['moving_mean'].detach().cpu().numpy().copy()
+            w[name + '/moving_variance'] = st['moving_var'].detach().cpu().numpy().copy()
         return split_heads(w)
 
     def get_grads(self) -> Dict[str, np.ndarray]:
@@ -388,8 +418,75 @@ class VAEEngine:
                 L.check(rc, fn)
         return run
 
+    # ---- BatchNormalization ops (use_batch_norm=True) ------------------------------------------------------------
+    def _bn_args(self, name: str, x: Buf, mode: int, grad: Optional[L.Seq] = None, dst: Optional[L.Seq] = None, sel=None,
+                 sel_bstride: int = 0, sel_cp: int = 0, keep=None, train: bool = True, sel_out=None) -> L.BnArgs:
+        st = self.bn[name]
+        mean, var = (st['mean'], st['var']) if train else (st['moving_mean'], st['moving_var'])
+        return L.BnArgs(x.seq(), mode, grad if grad is not None else _null_seq(), sel, sel_bstride, sel_cp, keep, 1.0 / KEEP_PROB,
+                        mean.data_ptr(), var.data_ptr(), BN_EPS, self._pslice(name + '/gamma'), self._pslice(name + '/beta'),
+                        st['sums_b'].data_ptr(), self.Bg * x.len, dst if dst is not None else _null_seq(), sel_out)
+
+    def _bn_sync_sums(self, t: torch.Tensor):
+        """Data parallel: the sums of the normalisation run over the GLOBAL batch (one small all-reduce each)."""
+        if self.world > 1:
+            if self._dp_all_reduce is None:
+                raise L.C1VError('use_batch_norm with world_size > 1 needs the all_reduce callable of train_step')
+            w = self._dp_all_reduce(t)
+            if w is not None and hasattr(w, 'wait'):
+                w.wait()
+
+    def _bn_fwd_ops(self, name: str, x: Buf, mode: int, dst: L.Seq, train: bool, sel_out=None, sel_bstride=0, sel_cp=0, keep=None):
+        """Ops that turn the conv output `x` into the pooled / upsampled, normalised input of the next layer."""
+        st = self.bn[name]
+        a = self._bn_args(name, x, mode, dst=dst, sel_bstride=sel_bstride, sel_cp=sel_cp, keep=keep, train=train, sel_out=sel_out)
+        self._keep.append(a)
+        f_red, f_stats, f_app = self.lib.c1v_bn_reduce, self.lib.c1v_bn_stats, self.lib.c1v_bn_apply_fwd
+        ref = C.byref(a)
+        n_global = self.Bg * x.len
+
+        def reduce_():
+            L.check(f_red(ref, 0, st['partial'].data_ptr(), L.BN_BLOCKS, st['sums_f'].data_ptr(), 1.0, self._stream()), 'c1v_bn_reduce')
+
+        def sync():
+            self._bn_sync_sums(st['sums_f'])
+        sync.bn_sync = st['sums_f']               # (tests emulate the all-reduce of several ranks on one GPU through this)
+
+        def stats():
+            L.check(f_stats(st['sums_f'].data_ptr(), st['C'], n_global, BN_EPS, BN_MOMENTUM, st['mean'].data_ptr(), st['var'].data_ptr(),
+                            st['moving_mean'].data_ptr(), st['moving_var'].data_ptr(), self._stream()), 'c1v_bn_stats')
+
+        def apply():
+            L.check(f_app(ref, self._stream()), 'c1v_bn_apply_fwd')
+        return ([reduce_, sync, stats] if train else []) + [apply]
+
+    def _bn_bwd_ops(self, name: str, x: Buf, mode: int, grad: L.Seq, dst: L.Seq, sel=None, sel_bstride=0, sel_cp=0, keep=None):
+        """Ops that turn the gradient w.r.t. the pooled / upsampled tensor into the gradient at the conv's pre-activation
+        (dst) and leave the gradients of gamma / beta in the layer's `slab` (beta first, then gamma)."""
+        st = self.bn[name]
+        a = self._bn_args(name, x, mode, grad=grad, dst=dst, sel=sel, sel_bstride=sel_bstride, sel_cp=sel_cp, keep=keep, train=True)
+        self._keep.append(a)
+        f_red, f_app = self.lib.c1v_bn_reduce, self.lib.c1v_bn_apply_bwd
+        ref = C.byref(a)
+
+        def reduce_():
+            L.check(f_red(ref, 1, st['partial'].data_ptr(), L.BN_BLOCKS, st['sums_b'].data_ptr(), 1.0, self._stream()), 'c1v_bn_reduce')
+
+        def sync():
+            self._bn_sync_sums(st['sums_b'])
+        sync.bn_sync = st['sums_b']
+
+        def share():
+            # the flat gradient is summed over the ranks once more later: hand it this rank's share of the global sums
+            torch.mul(st['sums_b'], 1.0 / self.world, out=st['slab'])
+
+        def apply():
+            L.check(f_app(ref, self._stream()), 'c1v_bn_apply_bwd')
+        return [reduce_, sync, share, apply]
+
     def _build_ops(self):
         g, k, B = self.g, self.g.kernel_size, self.B
+        bn = g.use_batch_norm
         nl = len(g.n_filters)
         nd = len(g.dec_filters)
         self._keep = []
@@ -408,11 +505,18 @@ class VAEEngine:
                 dstb = self.H if last else self.Xe[l + 1]
                 dst = dstb.seq(length=g.enc_len_pool[l])
                 keep = self.keep_e.data_ptr() if (train and last) else None
-                e = self._epi(dst, L.ROW_POOL2, self._bias_ptr('encoder_conv1d_%d/bias' % (l + 1)), 1,
-                              sel=self.sel[l].data_ptr(), sel_bstride=g.enc_len_pool[l] * F, sel_cp=F,
-                              keep=keep, keep_scale=1.0 / KEEP_PROB)
+                if bn:
+                    # conv (+ bias, ReLU) stored as it is; the normalisation then pools (and drops out) into the next buffer
+                    e = self._epi(self.Ae[l].seq(), L.ROW_STORE, self._bias_ptr('encoder_conv1d_%d/bias' % (l + 1)), 1)
+                else:
+                    e = self._epi(dst, L.ROW_POOL2, self._bias_ptr('encoder_conv1d_%d/bias' % (l + 1)), 1,
+                                  sel=self.sel[l].data_ptr(), sel_bstride=g.enc_len_pool[l] * F, sel_cp=F,
+                                  keep=keep, keep_scale=1.0 / KEEP_PROB)
                 ops.append(op('c1v_conv1d_fwd', L.ConvArgs(self.Xe[l].seq(), 0, g.enc_len_conv[l], k,
                                                            self.wop['enc%d_fwd' % l].data_ptr(), self.wld['enc%d_fwd' % l], F, e)))
+                if bn:
+                    ops += self._bn_fwd_ops('encoder_batchnorm_%d' % (l + 1), self.Ae[l], L.BN_POOL2, dst, train,
+                                            sel_out=self.sel[l].data_ptr(), sel_bstride=g.enc_len_pool[l] * F, sel_cp=F, keep=keep)
             mlv_seq = L.Seq(self.mlv.data_ptr(), L.F32, B, 2 * self.D, 0, 1, 2 * self.D, 2 * self.D)
             e = self._epi(mlv_seq, L.ROW_STORE, self._bias_ptr('z_heads/bias'))
             ops.append(op('c1v_dense_fwd', L.DenseArgs(self.H.t.data_ptr(), self.code, B, self.flat_p, self.flat_p,
@@ -432,7 +536,7 @@ class VAEEngine:
         self._lat_eval = latent(False, True)
         self._lat_infer = latent(False, False)
 
-        def dec_fwd():
+        def dec_fwd(train: bool):
             ops = []
             padded = self.width_p != g.width
             e = self._epi(self.Xd[0].seq(), L.ROW_STORE, self._bias_ptr('deconv_decoder_dense/bias'), 1, reshape_w=self.width_p,
@@ -444,11 +548,17 @@ class VAEEngine:
                 last = i == nd - 1
                 dstb = self.Xf if last else self.Xd[i + 1]
                 dst_len = g.output_text_size if last else 2 * g.dec_len_deconv[i]
-                e = self._epi(dstb.seq(length=dst_len), L.ROW_UP2,
-                              self._bias_ptr('deconv_decoder_%d_deconv1d_part2/bias' % (i + 1)), 1)
+                if bn:
+                    e = self._epi(self.Ad[i].seq(), L.ROW_STORE, self._bias_ptr('deconv_decoder_%d_deconv1d_part2/bias' % (i + 1)), 1)
+                else:
+                    e = self._epi(dstb.seq(length=dst_len), L.ROW_UP2,
+                                  self._bias_ptr('deconv_decoder_%d_deconv1d_part2/bias' % (i + 1)), 1)
                 ops.append(op('c1v_deconv1d_fwd', L.ConvArgs(self.Xd[i].seq(), 0, g.dec_len_deconv[i], k,
                                                              self.wop['dec%d_fwd' % i].data_ptr(), self.wld['dec%d_fwd' % i],
                                                              g.dec_filters[i], e)))
+                if bn:
+                    ops += self._bn_fwd_ops('deconv_decoder_batchnorm_%d' % (i + 1), self.Ad[i], L.BN_UP2,
+                                            dstb.seq(length=dst_len), train)
             e = self._epi(self.Y.seq(), L.ROW_STORE, self._bias_ptr('deconv_decoder_embeddings/bias'))
             ops.append(op('c1v_conv1d_fwd', L.ConvArgs(self.Xf.seq(), 0, g.output_text_size, k,
                                                        self.wop['out_fwd'].data_ptr(), self.wld['out_fwd'], self.V, e)))
@@ -462,7 +572,9 @@ class VAEEngine:
         self.ops_lat_train = [op('c1v_latent_head_fwd', self._lat_train)]
         self.ops_lat_eval = [op('c1v_latent_head_fwd', self._lat_eval)]
         self.ops_lat_infer = [op('c1v_latent_head_fwd', self._lat_infer)]
-        self.ops_dec = dec_fwd()
+        self.ops_dec_train = dec_fwd(True)
+        self.ops_dec_infer = dec_fwd(False) if bn else self.ops_dec_train
+        self.ops_dec = self.ops_dec_train
         self.ops_post = []
         f_eos = self.lib.c1v_eos_truncate_normalize
 
@@ -576,8 +688,20 @@ class VAEEngine:
                 fused = side + main
             stages.append((main, side, fused))
 
+        def bn_slabs(name: str, frozen=False):
+            """gamma / beta gradients = the two sums of the normalisation's backward reduction (beta first)."""
+            st = self.bn[name]
+            ch = st['C']
+            for w_, o_ in (('/beta', 0), ('/gamma', ch)):
+                segs.append(L.SegDesc(st['slab'].data_ptr() + 4 * o_, ch, 1, 1, 0, self.seg_off[name + w_], ch, 1 if frozen else 0, fblk[0]))
+                seg_names.append(name + w_)
+                fblk[0] += (ch + L.CHUNK - 1) // L.CHUNK
+
         C_last = g.dec_filters[-1]
-        e = self._epi(self.dOd[nd - 1].seq(), L.ROW_PAIRSUM, act=self.Xf.seq(), act_rowmul=2, act_scale=1.0)
+        if bn:
+            e = self._epi(self.dUd[nd - 1].seq(), L.ROW_STORE)
+        else:
+            e = self._epi(self.dOd[nd - 1].seq(), L.ROW_PAIRSUM, act=self.Xf.seq(), act_rowmul=2, act_scale=1.0)
         stage(('c1v_conv1d_dgrad', L.ConvArgs(self.dOf.seq(), g.pad_left, g.output_text_size, k,
                                               self.wop['out_dg'].data_ptr(), self.wld['out_dg'], C_last, e)),
               conv_wgrad(self.Xf, self.dOf, 'deconv_decoder_embeddings/kernel', 'deconv_decoder_embeddings/bias',
@@ -587,12 +711,20 @@ class VAEEngine:
             F = g.dec_filters[i]
             nm = 'deconv_decoder_%d_deconv1d_part2' % (i + 1)
             wg = conv_wgrad(self.Xd[i], self.dOd[i], nm + '/kernel', nm + '/bias', C_in, F, 1, F * C_in, 1, C_in)
-            if i > 0:
+            pre = []
+            if bn:
+                bname = 'deconv_decoder_batchnorm_%d' % (i + 1)
+                pre = self._bn_bwd_ops(bname, self.Ad[i], L.BN_UP2, self.dUd[i].seq(), self.dOd[i].seq())
+                bn_slabs(bname)
+            if i > 0 and bn:
+                e = self._epi(self.dUd[i - 1].seq(), L.ROW_STORE)
+            elif i > 0:
                 e = self._epi(self.dOd[i - 1].seq(), L.ROW_PAIRSUM, act=self.Xd[i].seq(), act_rowmul=2, act_scale=1.0)
             else:
                 e = self._epi(self.dDense.seq(), L.ROW_STORE, act=self.Xd[0].seq(), act_rowmul=1, act_scale=1.0)
             stage(('c1v_deconv1d_dgrad', L.ConvArgs(self.dOd[i].seq(), k - 1, g.dec_in_len[i], k,
-                                                    self.wop['dec%d_dg' % i].data_ptr(), self.wld['dec%d_dg' % i], C_in, e)), wg)
+                                                    self.wop['dec%d_dg' % i].data_ptr(), self.wld['dec%d_dg' % i], C_in, e)), wg,
+                  before=pre)
         wg = dense_wgrad(self.zd.data_ptr(), self.Dp, self.D, self.dDense.t.data_ptr(), self.nd_p, self.nd,
                          'deconv_decoder_dense/kernel', 'deconv_decoder_dense/bias')
         if not self.frozen and self.D % 4 == 0 and os.environ.get('C1V_LATENT_FUSE', '1') == '1':
@@ -618,8 +750,12 @@ class VAEEngine:
         dg = None
         if not self.frozen:
             F = g.n_filters[-1]
-            e = self._epi(self.dOe[nl - 1].seq(), L.ROW_UNPOOL, reshape_w=F, act=self.H.seq(), act_scale=1.0 / KEEP_PROB,
-                          sel=self.sel[nl - 1].data_ptr(), sel_bstride=g.enc_len_pool[nl - 1] * F, sel_cp=F)
+            if bn:
+                # gradient of the pooled (and dropped-out) output; the normalisation's backward un-pools and applies the mask
+                e = self._epi(self.dPe[nl - 1].seq(), L.ROW_STORE, reshape_w=F)
+            else:
+                e = self._epi(self.dOe[nl - 1].seq(), L.ROW_UNPOOL, reshape_w=F, act=self.H.seq(), act_scale=1.0 / KEEP_PROB,
+                              sel=self.sel[nl - 1].data_ptr(), sel_bstride=g.enc_len_pool[nl - 1] * F, sel_cp=F)
             dg = ('c1v_dense_dgrad', L.DenseArgs(self.dmlv.data_ptr(), self.code, B, self.D2p, self.D2p,
                                                  self.wop['heads_dg'].data_ptr(), self.wld['heads_dg'], self.flat, e))
         stage(dg, wg)
@@ -628,14 +764,26 @@ class VAEEngine:
             F = g.n_filters[l]
             nm = 'encoder_conv1d_%d' % (l + 1)
             wg = conv_wgrad(self.Xe[l], self.dOe[l], nm + '/kernel', nm + '/bias', C_in, F, 0, C_in * F, F, 1, self.frozen)
+            pre = []
+            if bn:
+                bname = 'encoder_batchnorm_%d' % (l + 1)
+                bn_slabs(bname, self.frozen)
+                if not self.frozen:
+                    last = l == nl - 1
+                    pre = self._bn_bwd_ops(bname, self.Ae[l], L.BN_POOL2, self.dPe[l].seq(), self.dOe[l].seq(),
+                                           sel=self.sel[l].data_ptr(), sel_bstride=g.enc_len_pool[l] * F, sel_cp=F,
+                                           keep=self.keep_e.data_ptr() if last else None)
             dg = None
             if l > 0 and not self.frozen:
                 Fp = g.n_filters[l - 1]
-                e = self._epi(self.dOe[l - 1].seq(), L.ROW_UNPOOL, act=self.Xe[l].seq(), act_scale=1.0,
-                              sel=self.sel[l - 1].data_ptr(), sel_bstride=g.enc_len_pool[l - 1] * Fp, sel_cp=Fp)
+                if bn:
+                    e = self._epi(self.dPe[l - 1].seq(), L.ROW_STORE)
+                else:
+                    e = self._epi(self.dOe[l - 1].seq(), L.ROW_UNPOOL, act=self.Xe[l].seq(), act_scale=1.0,
+                                  sel=self.sel[l - 1].data_ptr(), sel_bstride=g.enc_len_pool[l - 1] * Fp, sel_cp=Fp)
                 dg = ('c1v_conv1d_dgrad', L.ConvArgs(self.dOe[l].seq(), 0, g.enc_in_len[l], k,
                                                      self.wop['enc%d_dg' % l].data_ptr(), self.wld['enc%d_dg' % l], Fp, e))
-            stage(dg, wg)
+            stage(dg, wg, before=pre)
         self.bwd_stages = stages
         self.side_stream = torch.cuda.Stream(self.dev)
 
@@ -686,7 +834,7 @@ class VAEEngine:
         # C2 with three buckets: decoder side (0.8 MB) after nd+2 stages, the latent heads (3.9 MB, the bulk of the model)
         # after the next stage -- on the wire while the encoder convolutions' backward and its finalize run -- and the
         # encoder convolutions (0.5 MB) at the end; C1V_DP_BUCKETS=2 keeps heads + encoder convolutions in one bucket.
-        is_conv = lambda n: n.startswith('encoder_conv1d_')
+        is_conv = lambda n: n.startswith(('encoder_conv1d_', 'encoder_batchnorm_'))
         is_heads = lambda n: n.startswith('z_heads')
         is_enc = lambda n: is_conv(n) or is_heads(n)
         off_h, off_d = self.seg_off['z_heads/kernel'], self.seg_off['deconv_decoder_dense/kernel']
@@ -783,11 +931,15 @@ class VAEEngine:
             self._graphs[key] = gr
         gr.replay()
 
+    def _state_tensors(self):
+        bn = [st[k_] for st in self.bn.values() for k_ in ('moving_mean', 'moving_var')]
+        return [self.params, self.nadam_m, self.nadam_v, self.nadam_state, self.step_ctr] + bn
+
     def _save_state(self):
-        return [t.clone() for t in (self.params, self.nadam_m, self.nadam_v, self.nadam_state, self.step_ctr)]
+        return [t.clone() for t in self._state_tensors()]
 
     def _restore_state(self, saved):
-        for t, s in zip((self.params, self.nadam_m, self.nadam_v, self.nadam_state, self.step_ctr), saved):
+        for t, s in zip(self._state_tensors(), saved):
             t.copy_(s)
         self._pack_all()
 
@@ -826,7 +978,7 @@ class VAEEngine:
     def _run_backward(self, lo: int = 0, hi: Optional[int] = None):
         """Stages [lo, hi) of backward: one paired dgrad + wgrad launch per stage (default), or the dgrad chain on the
         current stream with the wgrads (and the loss scalars) on the side stream, joined at the end."""
-        if os.environ.get('C1V_BWD_PAIR', '1') == '1':
+        if os.environ.get('C1V_BWD_PAIR', '1') == '1' or self.g.use_batch_norm:
             for _, _, fused_ops in self.bwd_stages[lo:hi]:
                 self._run(fused_ops)
             return
@@ -874,10 +1026,10 @@ class VAEEngine:
     def forward_ops(self, with_rng: bool, from_ids: bool = False, advance: bool = False):
         """advance: the step ends in update_ops() (the fused prologue then also prepares the Nadam schedule)."""
         if self._fused_prologue():
-            return [self._prologue_op(with_rng, from_ids, advance)] + self.ops_enc_train + self.ops_lat_train + self.ops_dec + \
+            return [self._prologue_op(with_rng, from_ids, advance)] + self.ops_enc_train + self.ops_lat_train + self.ops_dec_train + \
                 self.ops_loss_train_core
         return (self.ops_rng if with_rng else []) + self._in_ops(from_ids) + self.ops_enc_train + self.ops_lat_train + \
-            self.ops_dec + self.ops_loss_train
+            self.ops_dec_train + self.ops_loss_train
 
     def train_ops(self, with_rng: bool, from_ids: bool = False, advance: bool = False):
         return self.forward_ops(with_rng, from_ids, advance) + [self._run_backward] + self.ops_finalize
@@ -896,6 +1048,7 @@ class VAEEngine:
         Every loss term already carries 1/B_global, so the sum IS the full-batch gradient."""
         if self.N == 0:
             raise L.C1VError('train_step needs the vocabulary matrix (set_vocab)')
+        self._dp_all_reduce = all_reduce
         sfx = '@ids' if from_ids else ''
 
         def go(key, ops):
@@ -963,7 +1116,7 @@ class VAEEngine:
         """Validation loss of the resident batch (dropout off, eps still sampled -- Keras test phase of FullVAE)."""
         self._ensure_packed()
         ops = ([] if fixed_rng else self.ops_rng_eval) + self._in_ops(from_ids) + self.ops_enc_infer + self.ops_lat_eval + \
-            self.ops_dec + self.ops_loss_eval
+            self.ops_dec_infer + self.ops_loss_eval
         if use_graph:
             self._graph(('eval_fixed' if fixed_rng else 'eval') + ('@ids' if from_ids else ''), ops)
         else:
@@ -973,7 +1126,7 @@ class VAEEngine:
         """FullVAE.predict_on_batch (:1462-1464): dropout off, z SAMPLED (the stage-2 generator trains on these), then
         optionally postprocess_reconstructed_word_vectors."""
         self._ensure_packed()
-        ops = self.ops_rng_eval + self._in_ops(from_ids) + self.ops_enc_infer + self.ops_lat_eval + self.ops_dec + \
+        ops = self.ops_rng_eval + self._in_ops(from_ids) + self.ops_enc_infer + self.ops_lat_eval + self.ops_dec_infer + \
             (self.ops_post if postprocess else [])
         if use_graph:
             self._graph('sample_recon' + ('_post' if postprocess else '') + ('@ids' if from_ids else ''), ops)
@@ -997,7 +1150,7 @@ class VAEEngine:
     def reconstruct(self, use_graph: bool = True, postprocess: bool = True) -> torch.Tensor:
         """vae_decoder_(vae_encoder_(x)) (:440) and, optionally, postprocess_reconstructed_word_vectors (:439)."""
         self._ensure_packed()
-        ops = self.ops_pack_in + self.ops_enc_infer + self.ops_lat_infer + self.ops_dec + (self.ops_post if postprocess else [])
+        ops = self.ops_pack_in + self.ops_enc_infer + self.ops_lat_infer + self.ops_dec_infer + (self.ops_post if postprocess else [])
         if use_graph:
             self._graph('recon_post' if postprocess else 'recon', ops)
         else:
@@ -1010,7 +1163,7 @@ class VAEEngine:
         self._ensure_packed()               # a train step leaves the refresh of the operand copies to the next prologue
         self.mlv_parts.zero_()
         self.mlv[:, :self.D].copy_(z)
-        self._run(self.ops_lat_infer + self.ops_dec)
+        self._run(self.ops_lat_infer + self.ops_dec_infer)
         return self.Y.t[: self.B * self.g.output_text_size * self.V].view(self.B, self.g.output_text_size, self.V)
 
     def y_pred(self) -> torch.Tensor:

@@ -39,7 +39,7 @@ FITTED_ATTRIBUTES = ['input_text_size_', 'output_text_size_', 'input_vector_size
 # layers of 'EncoderForVAE' = Model(encoder_input, z_mean) (:1308): what `vae_encoder_` saves, pickles and hands to a warm start.
 # The z_log_var head belongs to neither saved model: after unpickling / in a warm start it is freshly initialised, as in the
 # reference (whose rebuilt graph gives it new random weights, frozen in a warm start, :1245).
-ENCODER_PREFIXES = ('encoder_conv1d_', 'z_mean')
+ENCODER_PREFIXES = ('encoder_conv1d_', 'encoder_batchnorm_', 'z_mean')
 UNSAVED_PREFIXES = ('z_log_var',)
 
 
@@ -370,9 +370,6 @@ class Conv1dTextVAE(BaseEstimator, TransformerMixin, ClassifierMixin):
             if len(y) != len(X):
                 raise ValueError('Length of `X` does not equal to length of `y`! {0} != {1}.'.format(len(X), len(y)))
             y_ = y
-        if self.use_batch_norm:
-            raise NotImplementedError('use_batch_norm=True is not available on the HIP path (it is off by default in the '
-                                      'reference and needs cross-GPU batch statistics).')
         if self.tokenizer is None:
             self.tokenizer = DefaultTokenizer()
         # the LAST round(n * validation_fraction) pairs are the evaluation set (:201-217); both parts must be non-empty
@@ -1041,7 +1038,7 @@ class Conv1dTextVAE(BaseEstimator, TransformerMixin, ClassifierMixin):
                       vae_weights: Optional[Dict[str, np.ndarray]] = None):
         from .seq2seq import Seq2SeqGenerator
         geom = Geometry(self.input_text_size_, self.output_text_size_, input_vector_size, output_vector_size,
-                        self.n_filters, self.kernel_size, self.latent_dim)
+                        self.n_filters, self.kernel_size, self.latent_dim, use_batch_norm=bool(self.use_batch_norm))
         weights = init_keras_weights(geom, seed)
         if vae_weights is not None:
             missing = set(k for k in weights if not k.startswith(UNSAVED_PREFIXES)) - set(vae_weights)

@@ -8,9 +8,14 @@ from typing import Dict, List, Tuple
 import numpy as np
 
 
+BN_WEIGHTS = ('gamma', 'beta', 'moving_mean', 'moving_variance')      # Keras BatchNormalization weight names
+BN_MOVING = ('/moving_mean', '/moving_variance')
+BN_MOMENTUM, BN_EPS = 0.99, 1e-3                                       # Keras 2.2 defaults
+
+
 class Geometry:
     def __init__(self, input_text_size: int, output_text_size: int, input_vector_size: int, output_vector_size: int,
-                 n_filters, kernel_size: int, latent_dim: int):
+                 n_filters, kernel_size: int, latent_dim: int, use_batch_norm: bool = False):
         if isinstance(n_filters, int):
             n_filters = (n_filters,)
         self.input_text_size = int(input_text_size)
@@ -20,6 +25,7 @@ class Geometry:
         self.n_filters = tuple(int(f) for f in n_filters)
         self.kernel_size = k = int(kernel_size)
         self.latent_dim = int(latent_dim)
+        self.use_batch_norm = bool(use_batch_norm)       # BatchNormalization behind every conv / transposed conv (:1229, :1259)
         # encoder: Conv1D('valid') -> MaxPool1D(2) per layer (:1227-1241)
         self.enc_in_len: List[int] = []
         self.enc_len_conv: List[int] = []
@@ -64,6 +70,9 @@ class Geometry:
         for i, f in enumerate(self.n_filters):
             s['encoder_conv1d_%d/kernel' % (i + 1)] = (k, c, f)
             s['encoder_conv1d_%d/bias' % (i + 1)] = (f,)
+            if self.use_batch_norm:
+                for w in BN_WEIGHTS:
+                    s['encoder_batchnorm_%d/%s' % (i + 1, w)] = (f,)
             c = f
         s['z_mean/kernel'] = (self.flat_size, self.latent_dim)
         s['z_mean/bias'] = (self.latent_dim,)
@@ -75,6 +84,9 @@ class Geometry:
         for i, f in enumerate(self.dec_filters):
             s['deconv_decoder_%d_deconv1d_part2/kernel' % (i + 1)] = (k, 1, f, c)
             s['deconv_decoder_%d_deconv1d_part2/bias' % (i + 1)] = (f,)
+            if self.use_batch_norm:
+                for w in BN_WEIGHTS:
+                    s['deconv_decoder_batchnorm_%d/%s' % (i + 1, w)] = (f,)
             c = f
         s['deconv_decoder_embeddings/kernel'] = (k, c, self.output_vector_size)
         s['deconv_decoder_embeddings/bias'] = (self.output_vector_size,)
@@ -85,7 +97,7 @@ class Geometry:
         so that both heads are a single GEMM; `split_heads` / `merge_heads` convert to the Keras pair."""
         out: List[Tuple[str, Tuple[int, ...]]] = []
         for name, shape in self.keras_shapes().items():
-            if name.startswith('z_log_var'):
+            if name.startswith('z_log_var') or name.endswith(BN_MOVING):       # moving averages are not trainable
                 continue
             if name == 'z_mean/kernel':
                 out.append(('z_heads/kernel', (self.flat_size, 2 * self.latent_dim)))
@@ -99,7 +111,14 @@ class Geometry:
         return int(sum(int(np.prod(s)) for _, s in self.segments()))
 
     def encoder_names(self) -> List[str]:
-        return [n for n, _ in self.segments() if n.startswith('encoder_conv1d_') or n.startswith('z_heads')]
+        return [n for n, _ in self.segments() if n.startswith(('encoder_conv1d_', 'encoder_batchnorm_', 'z_heads'))]
+
+    def bn_layers(self) -> List[Tuple[str, int]]:
+        """(Keras layer name, channels) of every BatchNormalization layer, encoder first."""
+        if not self.use_batch_norm:
+            return []
+        return [('encoder_batchnorm_%d' % (i + 1), f) for i, f in enumerate(self.n_filters)] + \
+               [('deconv_decoder_batchnorm_%d' % (i + 1), f) for i, f in enumerate(self.dec_filters)]
 
 
 def glorot_limit(shape: Tuple[int, ...]) -> float:
@@ -118,8 +137,10 @@ def init_keras_weights(geom: Geometry, seed: int = 0) -> Dict[str, np.ndarray]:
     rng = np.random.Generator(np.random.PCG64(seed))
     w: Dict[str, np.ndarray] = {}
     for name, shape in geom.keras_shapes().items():
-        if name.endswith('/bias'):
+        if name.endswith(('/bias', '/beta', '/moving_mean')):
             w[name] = np.zeros(shape, dtype=np.float32)
+        elif name.endswith(('/gamma', '/moving_variance')):
+            w[name] = np.ones(shape, dtype=np.float32)
         else:
             lim = glorot_limit(shape)
             w[name] = rng.uniform(-lim, lim, size=shape).astype(np.float32)

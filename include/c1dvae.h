@@ -195,6 +195,43 @@ int c1v_pack_input(const c1v_pack_input_args*, void* stream);
 typedef struct c1v_gather_input_args { const float* table; int64_t ld; const int32_t* ids; int32_t T, C; c1v_seq dst; } c1v_gather_input_args;
 int c1v_gather_input(const c1v_gather_input_args*, void* stream);
 
+/* ---- BatchNormalization (use_batch_norm=True: :1229-1230, :1238-1239, :1259-1260, :1270-1272) ----------------------------
+ * Keras 2.2 defaults: axis -1, momentum 0.99, epsilon 1e-3.  The layer normalises a convolution's post-ReLU output x
+ * [B][len][C] per channel and is followed by MaxPool1D(2) (encoder: C1V_BN_POOL2) or UpSampling1D(2) + Cropping1D
+ * (decoder: C1V_BN_UP2), which the kernels apply themselves.
+ *   c1v_bn_reduce(backward = 0): sums[0][c] = sum x, sums[1][c] = sum x^2 over (b, t)        (times sum_scale)
+ *   c1v_bn_reduce(backward = 1): sums[0][c] = sum dy, sums[1][c] = sum dy * xhat, dy = gradient w.r.t. the normalised
+ *       output, obtained on the fly from `grad` (POOL2: gradient of the pooled output + sel (+ keep mask); UP2: gradient
+ *       of the upsampled, cropped output, rows 2t and 2t+1 summed)
+ *     two deterministic stages through `partial` ([blocks][2][C] floats).  Data-parallel ranks all-reduce `sums`.
+ *   c1v_bn_stats: mean, var (biased) from the sums of the GLOBAL batch (n_global rows); moving averages, if given:
+ *       moving = moving * momentum + (1 - momentum) * {mean, var * n / (n - (1 + eps))}
+ *   c1v_bn_apply_fwd: y = gamma * (x - mean) / sqrt(var + eps) + beta -> pool (writes sel_out, applies the keep mask) or
+ *       upsample into dst.  Inference passes the moving averages as mean / var.
+ *   c1v_bn_apply_bwd: dst(b, t, c) = [x > 0] * gamma / sqrt(var + eps) * (dy - sums[0] / n - xhat * sums[1] / n)
+ *       (the gradient at the convolution's pre-activation); gamma's gradient is sums[1], beta's is sums[0]. */
+#define C1V_BN_POOL2 1
+#define C1V_BN_UP2   2
+typedef struct c1v_bn_args {
+    c1v_seq x;                 /* post-ReLU conv output; x.len = rows per sample, x.c = channels */
+    int32_t mode;
+    c1v_seq grad;              /* backward only */
+    const uint8_t* sel;        /* POOL2 backward: which row of each pair was kept */
+    int64_t sel_bstride; int32_t sel_cp;     /* indexing of sel / sel_out / keep: b*sel_bstride + t2*sel_cp + c */
+    const uint8_t* keep; float keep_scale;   /* optional dropout keep mask on the POOLED output (forward and backward) */
+    const float* mean; const float* var; float eps;
+    const float* gamma; const float* beta;
+    const float* sums;         /* backward apply: [2][C] over the global batch */
+    int64_t n_global;          /* rows (b, t) of the global batch */
+    c1v_seq dst;               /* apply_fwd: pooled / upsampled output; apply_bwd: gradient buffer of the conv output */
+    uint8_t* sel_out;          /* apply_fwd POOL2: written */
+} c1v_bn_args;
+int c1v_bn_reduce(const c1v_bn_args*, int32_t backward, float* partial, int32_t blocks, float* sums, float sum_scale, void* stream);
+int c1v_bn_stats(const float* sums, int32_t C, int64_t n_global, float eps, float momentum, float* mean, float* var,
+                 float* moving_mean, float* moving_var, void* stream);
+int c1v_bn_apply_fwd(const c1v_bn_args*, void* stream);
+int c1v_bn_apply_bwd(const c1v_bn_args*, void* stream);
+
 /* ---- a3+a4: latent head (:1188-1191, :1202, :1246, :1254) ---------------------------------------------------
  * mlv [B][2*D] f32 (z_mean | z_log_var, bias already added by the dense epilogue)
  * fwd: z = m + exp(std_scale*lv)*eps ; zd = keep_d ? z/keep_prob : 0 -> zd_out (T, [B][ldz]); z_out f32 optional

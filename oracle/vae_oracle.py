@@ -32,6 +32,11 @@ NADAM_B1 = 0.9
 NADAM_B2 = 0.999
 NADAM_EPS = 1e-7          # K.epsilon()
 NADAM_SCHEDULE_DECAY = 0.004
+# Keras 2.2 BatchNormalization defaults (layers/normalization.py): axis -1, momentum 0.99, epsilon 1e-3, gamma ones,
+# beta zeros, moving_mean zeros, moving_variance ones
+BN_MOMENTUM = 0.99
+BN_EPS = 1e-3
+BN_WEIGHTS = ('gamma', 'beta', 'moving_mean', 'moving_variance')
 
 
 # ---------------------------------------------------------------------------------------------
@@ -46,6 +51,7 @@ class VAEGeometry:
     n_filters: Tuple[int, ...]
     kernel_size: int
     latent_dim: int
+    use_batch_norm: bool = False      # BatchNormalization after every conv / transposed conv (:1229-1230, :1259-1260)
 
     enc_len_conv: List[int] = field(default_factory=list)   # length after each valid conv
     enc_len_pool: List[int] = field(default_factory=list)   # length after each MaxPool1D(2)
@@ -100,6 +106,9 @@ class VAEGeometry:
         for i, f in enumerate(self.n_filters):
             shapes['encoder_conv1d_%d/kernel' % (i + 1)] = (k, c_in, f)
             shapes['encoder_conv1d_%d/bias' % (i + 1)] = (f,)
+            if self.use_batch_norm:
+                for w in BN_WEIGHTS:
+                    shapes['encoder_batchnorm_%d/%s' % (i + 1, w)] = (f,)
             c_in = f
         shapes['z_mean/kernel'] = (self.flat_size, self.latent_dim)
         shapes['z_mean/bias'] = (self.latent_dim,)
@@ -111,6 +120,9 @@ class VAEGeometry:
         for i, f in enumerate(self.dec_filters):
             shapes['deconv_decoder_%d_deconv1d_part2/kernel' % (i + 1)] = (k, 1, f, c_in)   # (kh, kw, out, in)
             shapes['deconv_decoder_%d_deconv1d_part2/bias' % (i + 1)] = (f,)
+            if self.use_batch_norm:
+                for w in BN_WEIGHTS:
+                    shapes['deconv_decoder_batchnorm_%d/%s' % (i + 1, w)] = (f,)
             c_in = f
         shapes['deconv_decoder_embeddings/kernel'] = (k, c_in, self.output_vector_size)
         shapes['deconv_decoder_embeddings/bias'] = (self.output_vector_size,)
@@ -136,8 +148,10 @@ def init_params(geom: VAEGeometry, seed: int = 0, dtype=np.float32) -> Dict[str,
     rng = np.random.Generator(np.random.PCG64(seed))
     params = {}
     for name, shape in geom.param_shapes().items():
-        if name.endswith('/bias'):
+        if name.endswith(('/bias', '/beta', '/moving_mean')):
             params[name] = np.zeros(shape, dtype=dtype)
+        elif name.endswith(('/gamma', '/moving_variance')):
+            params[name] = np.ones(shape, dtype=dtype)
         else:
             lim = _glorot_limit(shape)
             params[name] = rng.uniform(-lim, lim, size=shape).astype(dtype)
@@ -236,17 +250,62 @@ def upsample2_bwd(dout):
     return dout.reshape(B, L2 // 2, 2, F).sum(axis=2)
 
 
+def batchnorm_fwd(x, params, name, training, cache=None, key=None):
+    """Keras 2.2 BatchNormalization over the last axis of x [B, L, C] (:1229-1230, :1259-1260).
+    training: statistics of THIS batch over (B, L) (biased variance) normalise it; the moving averages move by
+    (1 - momentum) towards the batch mean and towards the batch variance scaled by n / (n - (1 + eps)) (Keras' "sample
+    variance" correction).  Otherwise the moving averages normalise.  Returns (y, new moving averages or None)."""
+    gamma, beta = params[name + '/gamma'], params[name + '/beta']
+    if training:
+        n = x.shape[0] * x.shape[1]
+        mean = x.mean(axis=(0, 1))
+        var = x.var(axis=(0, 1))
+        rstd = 1.0 / np.sqrt(var + BN_EPS)
+        xhat = (x - mean) * rstd
+        moving = (params[name + '/moving_mean'] * BN_MOMENTUM + mean * (1.0 - BN_MOMENTUM),
+                  params[name + '/moving_variance'] * BN_MOMENTUM + var * (n / (n - (1.0 + BN_EPS))) * (1.0 - BN_MOMENTUM))
+    else:
+        rstd = 1.0 / np.sqrt(params[name + '/moving_variance'] + BN_EPS)
+        xhat = (x - params[name + '/moving_mean']) * rstd
+        moving = None
+    if cache is not None:
+        cache[key + '_xhat'] = xhat
+        cache[key + '_rstd'] = rstd
+    return xhat * gamma + beta, moving
+
+
+def batchnorm_bwd(dy, xhat, rstd, gamma):
+    """Gradient of the training-mode normalisation: (dx, dgamma, dbeta)."""
+    n = dy.shape[0] * dy.shape[1]
+    dbeta = dy.sum(axis=(0, 1))
+    dgamma = (dy * xhat).sum(axis=(0, 1))
+    dx = (gamma * rstd) * (dy - dbeta / n - xhat * (dgamma / n))
+    return dx, dgamma, dbeta
+
+
 # ---------------------------------------------------------------------------------------------
 # full model: forward / loss / backward
 # ---------------------------------------------------------------------------------------------
-def encoder_forward(geom: VAEGeometry, params, x, mask_e=None, cache: Optional[dict] = None):
-    """:1224-1245.  mask_e (bool [B, flat]) = dropout keep mask in training, None at inference (:1243)."""
+def encoder_forward(geom: VAEGeometry, params, x, mask_e=None, cache: Optional[dict] = None, training: bool = False,
+                    moving: Optional[dict] = None):
+    """:1224-1245.  mask_e (bool [B, flat]) = dropout keep mask in training, None at inference (:1243).
+    training / moving only matter with use_batch_norm: batch statistics are used and the new moving averages are put
+    into `moving` (name -> array)."""
     h = x
     for i in range(len(geom.n_filters)):
         W = params['encoder_conv1d_%d/kernel' % (i + 1)]
         b = params['encoder_conv1d_%d/bias' % (i + 1)]
         pre = conv1d_valid(h, W, b)
         act = np.maximum(pre, 0)
+        bn_in = act
+        if geom.use_batch_norm:
+            name = 'encoder_batchnorm_%d' % (i + 1)
+            act_n, mv = batchnorm_fwd(act, params, name, training, cache, 'enc_bn_%d' % i)
+            if moving is not None and mv is not None:
+                moving[name + '/moving_mean'], moving[name + '/moving_variance'] = mv
+            if cache is not None:
+                cache['enc_relu_%d' % i] = bn_in
+            act = act_n
         pooled, sel = maxpool2(act)
         if cache is not None:
             cache['enc_in_%d' % i] = h
@@ -267,7 +326,8 @@ def encoder_forward(geom: VAEGeometry, params, x, mask_e=None, cache: Optional[d
     return z_mean, z_log_var
 
 
-def decoder_forward(geom: VAEGeometry, params, z, mask_d=None, cache: Optional[dict] = None):
+def decoder_forward(geom: VAEGeometry, params, z, mask_d=None, cache: Optional[dict] = None, training: bool = False,
+                    moving: Optional[dict] = None):
     """DecoderForVAE :1252-1281."""
     if mask_d is not None:
         zd = z * mask_d.astype(z.dtype) / z.dtype.type(KEEP_PROB)      # :1254
@@ -287,6 +347,11 @@ def decoder_forward(geom: VAEGeometry, params, z, mask_d=None, cache: Optional[d
         if cache is not None:
             cache['dec_in_%d' % i] = d
             cache['dec_act_%d' % i] = a
+        if geom.use_batch_norm:
+            name = 'deconv_decoder_batchnorm_%d' % (i + 1)
+            a, mv = batchnorm_fwd(a, params, name, training, cache, 'dec_bn_%d' % i)
+            if moving is not None and mv is not None:
+                moving[name + '/moving_mean'], moving[name + '/moving_variance'] = mv
         d = upsample2(a)
     full_len = d.shape[1]
     d = d[:, :geom.output_text_size, :]                                # Cropping1D((0, c)) :1276-1278
@@ -366,9 +431,10 @@ def train_forward_backward(geom: VAEGeometry, params, W_vocab, x, target_ids, ep
     (chosen element > 0), `dec_on_i` bool [B, L, F], `dense_on` bool [B, n_t*width] -- replace this run's own choices in
     the backward pass, so that what is left of the difference between the two gradients is rounding, not flipped choices."""
     c: dict = {}
-    z_mean, z_log_var = encoder_forward(geom, params, x, mask_e, c)
+    moving: dict = {}
+    z_mean, z_log_var = encoder_forward(geom, params, x, mask_e, c, training=True, moving=moving)
     z = sampling(z_mean, z_log_var, eps)
-    y = decoder_forward(geom, params, z, mask_d, c)
+    y = decoder_forward(geom, params, z, mask_d, c, training=True, moving=moving)
     lc: dict = {}
     loss, xent_b, kl_b = vae_loss(y, W_vocab, target_ids, z_mean, z_log_var, cache=lc)
     dy, dm, dlv = vae_loss_bwd(y, W_vocab, target_ids, z_mean, z_log_var, lc)
@@ -383,6 +449,10 @@ def train_forward_backward(geom: VAEGeometry, params, W_vocab, x, target_ids, ep
     g = full
     for i in reversed(range(len(geom.dec_filters))):
         g = upsample2_bwd(g)
+        if geom.use_batch_norm:
+            bn = 'deconv_decoder_batchnorm_%d' % (i + 1)
+            g, grads[bn + '/gamma'], grads[bn + '/beta'] = batchnorm_bwd(g, c['dec_bn_%d_xhat' % i], c['dec_bn_%d_rstd' % i],
+                                                                         params[bn + '/gamma'])
         g = g * (decisions['dec_on_%d' % i] if decisions is not None else (c['dec_act_%d' % i] > 0))
         name = 'deconv_decoder_%d_deconv1d_part2' % (i + 1)
         g, dWt, db = deconv1d_valid_bwd(c['dec_in_%d' % i], params[name + '/kernel'], g)
@@ -407,7 +477,14 @@ def train_forward_backward(geom: VAEGeometry, params, W_vocab, x, target_ids, ep
     g = dflat.reshape(c['pool_shape'])
     for i in reversed(range(len(geom.n_filters))):
         act = c['enc_act_%d' % i]
-        if decisions is not None:
+        if geom.use_batch_norm:
+            # pool backward, then the normalisation, then the ReLU of the convolution in front of it
+            g = maxpool2_bwd(g, c['enc_sel_%d' % i], act.shape[1])
+            bn = 'encoder_batchnorm_%d' % (i + 1)
+            g, grads[bn + '/gamma'], grads[bn + '/beta'] = batchnorm_bwd(g, c['enc_bn_%d_xhat' % i], c['enc_bn_%d_rstd' % i],
+                                                                         params[bn + '/gamma'])
+            g = g * (c['enc_relu_%d' % i] > 0)
+        elif decisions is not None:
             g = maxpool2_bwd(g * decisions['enc_on_%d' % i], decisions['enc_sel_%d' % i], act.shape[1])
         else:
             g = maxpool2_bwd(g, c['enc_sel_%d' % i], act.shape[1])
@@ -421,7 +498,7 @@ def train_forward_backward(geom: VAEGeometry, params, W_vocab, x, target_ids, ep
             if name.startswith('encoder_conv1d_') or name.startswith('z_mean') or name.startswith('z_log_var'):
                 grads[name] = np.zeros_like(grads[name])
     acts = dict(z_mean=z_mean, z_log_var=z_log_var, z=z, y_pred=y, xent_b=xent_b, kl_b=kl_b, dy=dy,
-                flat=c['flat'], final_in=c['final_in'])
+                flat=c['flat'], final_in=c['final_in'], moving=moving)
     return float(loss), {k: v.astype(dt) for k, v in grads.items()}, acts
 
 
@@ -466,6 +543,8 @@ def nadam_step(params: Dict[str, np.ndarray], grads: Dict[str, np.ndarray], stat
     t = state.iterations + 1
     mu_t, mu_t1, m_new, m_next = nadam_schedule(t, state.m_schedule)
     for name, p in params.items():
+        if name not in grads:          # BatchNormalization moving averages: not trainable, moved by the forward pass
+            continue
         dt = p.dtype
         g = grads[name] * dt.type(scale)
         m = state.m.get(name)

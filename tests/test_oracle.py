@@ -78,6 +78,9 @@ def _torch_forward(geom, P, Wv, x, ids, eps, mask_e, mask_d):
         W = P['encoder_conv1d_%d/kernel' % (i + 1)]          # [k, C, F]
         b = P['encoder_conv1d_%d/bias' % (i + 1)]
         h = F.relu(F.conv1d(h, W.permute(2, 1, 0), b))
+        if geom.use_batch_norm:
+            nm = 'encoder_batchnorm_%d' % (i + 1)
+            h = F.batch_norm(h, None, None, P[nm + '/gamma'], P[nm + '/beta'], training=True, eps=O.BN_EPS)
         h = F.max_pool1d(h, 2)
     flat = h.permute(0, 2, 1).reshape(h.shape[0], -1)
     if mask_e is not None:
@@ -93,6 +96,9 @@ def _torch_forward(geom, P, Wv, x, ids, eps, mask_e, mask_d):
         b = P['deconv_decoder_%d_deconv1d_part2/bias' % (i + 1)]
         # torch conv_transpose1d weight: [C_in, C_out, k];  out[t] = sum_j x[t-j] w[:, :, j]
         d = F.relu(F.conv_transpose1d(d, Wt[:, 0].permute(2, 1, 0), b))
+        if geom.use_batch_norm:
+            nm = 'deconv_decoder_batchnorm_%d' % (i + 1)
+            d = F.batch_norm(d, None, None, P[nm + '/gamma'], P[nm + '/beta'], training=True, eps=O.BN_EPS)
         d = d.repeat_interleave(2, dim=2)
     d = d[:, :, :geom.output_text_size]
     Wo = P['deconv_decoder_embeddings/kernel']
@@ -153,6 +159,58 @@ def test_forward_backward_matches_torch_autograd(case, dropout):
     np.testing.assert_allclose(acts['y_pred'], y.detach().numpy(), rtol=1e-10, atol=1e-12)
     for name in params:
         np.testing.assert_allclose(grads[name], P[name].grad.numpy(), rtol=1e-8, atol=1e-12, err_msg=name)
+
+
+@pytest.mark.parametrize('case', CASES[:3])
+def test_batchnorm_forward_backward_matches_torch_autograd(case):
+    """use_batch_norm=True (:1229-1230, :1259-1260): Keras BatchNormalization in its training phase = normalisation by
+    the batch statistics over (B, L), which is torch's F.batch_norm(training=True); gradients of every weight, gamma and
+    beta included, against autograd; moving averages against the Keras update rule; inference against the moving averages."""
+    V = case['E'] + 2
+    geom = O.VAEGeometry(case['T_in'], case['T_out'], V, V, case['n_filters'], case['k'], case['D'], use_batch_norm=True)
+    params = O.init_params(geom, seed=3, dtype=np.float64)
+    rng = np.random.RandomState(0)
+    for name in params:
+        if name.endswith(('/bias', '/beta')):
+            params[name] = rng.uniform(-0.1, 0.1, params[name].shape)
+        elif name.endswith('/gamma'):
+            params[name] = rng.uniform(0.5, 1.5, params[name].shape) * rng.choice([-1.0, 1.0], params[name].shape)
+        elif name.endswith('/moving_mean'):
+            params[name] = rng.uniform(-0.2, 0.2, params[name].shape)
+        elif name.endswith('/moving_variance'):
+            params[name] = rng.uniform(0.5, 1.5, params[name].shape)
+    Wv = O.synthetic_vocab(case['N'] - 2, case['E'], seed=5, dtype=np.float64)
+    x, ids = O.synthetic_batch(Wv, Wv.shape[0], case['B'], case['T_in'], case['T_out'], seed=7)
+    eps = rng.standard_normal((case['B'], case['D']))
+    mask_e = rng.uniform(size=(case['B'], geom.flat_size)) < 0.7
+    mask_d = rng.uniform(size=(case['B'], case['D'])) < 0.7
+    loss, grads, acts = O.train_forward_backward(geom, params, Wv, x, ids, eps, mask_e, mask_d)
+    trainable = [k_ for k_ in params if not k_.endswith(('/moving_mean', '/moving_variance'))]
+    assert sorted(grads) == sorted(trainable)
+    P = {k_: torch.tensor(v, dtype=torch.float64, requires_grad=k_ in trainable) for k_, v in params.items()}
+    tl, zm, zl, y = _torch_forward(geom, P, torch.tensor(Wv), torch.tensor(x), ids, torch.tensor(eps),
+                                   torch.tensor(mask_e.astype(np.float64)), torch.tensor(mask_d.astype(np.float64)))
+    tl.backward()
+    assert abs(loss - tl.item()) < 1e-10 * max(1.0, abs(loss))
+    np.testing.assert_allclose(acts['y_pred'], y.detach().numpy(), rtol=1e-9, atol=1e-11)
+    for name in trainable:
+        np.testing.assert_allclose(grads[name], P[name].grad.numpy(), rtol=1e-7, atol=1e-11, err_msg=name)
+    # moving averages: momentum 0.99 towards the batch mean / the batch variance times n / (n - (1 + eps))
+    a0 = np.maximum(O.conv1d_valid(x, params['encoder_conv1d_1/kernel'], params['encoder_conv1d_1/bias']), 0)
+    n = a0.shape[0] * a0.shape[1]
+    want_mean = 0.99 * params['encoder_batchnorm_1/moving_mean'] + 0.01 * a0.mean(axis=(0, 1))
+    want_var = 0.99 * params['encoder_batchnorm_1/moving_variance'] + 0.01 * a0.var(axis=(0, 1)) * n / (n - 1.001)
+    np.testing.assert_allclose(acts['moving']['encoder_batchnorm_1/moving_mean'], want_mean, rtol=1e-12)
+    np.testing.assert_allclose(acts['moving']['encoder_batchnorm_1/moving_variance'], want_var, rtol=1e-12)
+    assert len(acts['moving']) == 2 * 2 * len(case['n_filters'])
+    # inference normalises with the moving averages (no batch coupling: one sample alone gives the same row)
+    zm_all, _ = O.encoder_forward(geom, params, x)
+    zm_one, _ = O.encoder_forward(geom, params, x[:1])
+    np.testing.assert_allclose(zm_all[:1], zm_one, rtol=1e-12, atol=1e-14)
+    # and a Nadam step leaves the moving averages to the forward pass
+    before = params['encoder_batchnorm_1/moving_mean'].copy()
+    O.nadam_step(params, grads, O.NadamState())
+    assert np.array_equal(before, params['encoder_batchnorm_1/moving_mean'])
 
 
 def test_loss_clip_kills_gradient():
