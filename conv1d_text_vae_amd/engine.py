@@ -208,11 +208,12 @@ class VAEEngine:
         if geom.use_batch_norm:
             for l in range(nl):
                 Fl = geom.n_filters[l]
-                self.Ae.append(seqbuf(B, _even(geom.enc_in_len[l] + k - 1), k - 1, geom.enc_len_conv[l], Fl))
+                # (fp32 whatever the compute dtype: statistics and normalisation then see un-rounded conv outputs)
+                self.Ae.append(seqbuf(B, _even(geom.enc_in_len[l] + k - 1), k - 1, geom.enc_len_conv[l], Fl, dt=torch.float32))
                 self.dPe.append(seqbuf(B, _even(geom.enc_len_pool[l]), 0, geom.enc_len_pool[l], Fl))
             for i, f in enumerate(geom.dec_filters):
                 nxt = self.Xf if i == len(geom.dec_filters) - 1 else self.Xd[i + 1]
-                self.Ad.append(seqbuf(B, _even(geom.dec_in_len[i] + 3 * (k - 1)), k - 1, geom.dec_len_deconv[i], f))
+                self.Ad.append(seqbuf(B, _even(geom.dec_in_len[i] + 3 * (k - 1)), k - 1, geom.dec_len_deconv[i], f, dt=torch.float32))
                 self.dUd.append(seqbuf(B, nxt.pitch, nxt.off, nxt.len, f))
         self.post = z(B, To, self.V - 1)
         self.end_idx = torch.zeros(B, dtype=torch.int32, device=self.dev)

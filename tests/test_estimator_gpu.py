@@ -312,3 +312,33 @@ def test_sequence_for_seq2seq_with_fake_vae(fasttext_model):
         assert gen_in[b, T + 1, char_index['<EOS>']] == 1.0
         assert gen_out[b, T, char_index['<EOS>']] == 1.0 and gen_out[b, T + 1, char_index['<EOS>']] == 1.0
         assert gen_in[b].sum() == T + 2 and gen_out[b].sum() == T + 2
+
+
+def test_fit_predict_with_batch_norm(fasttext_model, corpus, tmp_path):
+    """use_batch_norm=True (reference :148, :1229-1230, :1259-1260) end to end: the loss falls, the moving averages move
+    and travel through pickling, and inference (which normalises with them) is reproduced bit for bit after unpickling."""
+    from conv1d_text_vae_amd import Conv1dTextVAE
+    vae = Conv1dTextVAE(fasttext_model, fasttext_model, max_epochs=8, batch_size=2, n_filters=(24, 16), latent_dim=12,
+                        use_batch_norm=True)
+    vae.fit(corpus[0], corpus[1])
+    _assert_fitted(vae)
+    hist = vae.vae_history_
+    assert hist[-1]['loss'] < hist[0]['loss'] and np.isfinite(hist[-1]['val_loss'])
+    w = vae._vae_runtime.weights()
+    for name in ('encoder_batchnorm_1', 'encoder_batchnorm_2', 'deconv_decoder_batchnorm_1', 'deconv_decoder_batchnorm_2'):
+        for part in ('gamma', 'beta', 'moving_mean', 'moving_variance'):
+            assert name + '/' + part in w
+        assert np.abs(w[name + '/moving_mean']).max() > 0 and not np.allclose(w[name + '/moving_variance'], 1.0)
+    assert any(k.startswith('encoder_batchnorm_1') for k in vae.vae_encoder_.get_weights())
+    assert any(k.startswith('deconv_decoder_batchnorm_1') for k in vae.vae_decoder_.get_weights())
+    out = vae.predict(corpus[0][:3])
+    assert len(out) == 3 and all(isinstance(t, str) and len(t) > 0 for t in out)
+    z1 = vae.transform(corpus[0])
+    with open(str(tmp_path / 'bn.pkl'), 'wb') as fp:
+        pickle.dump(vae, fp)
+    with open(str(tmp_path / 'bn.pkl'), 'rb') as fp:
+        res = pickle.load(fp)
+    assert res.use_batch_norm is True
+    res.input_embeddings = res.output_embeddings = fasttext_model
+    np.testing.assert_array_equal(res.transform(corpus[0]), z1)
+    assert res.predict(corpus[0][:3]) == out
