@@ -17,6 +17,7 @@ from __future__ import annotations
 
 import copy
 import io
+import time
 import math
 import os
 import tempfile
@@ -911,8 +912,75 @@ class Conv1dTextVAE(BaseEstimator, TransformerMixin, ClassifierMixin):
 
     @staticmethod
     def quantize_word_vectors(word_vectors: np.ndarray, max_vocabulary_size: int, verbose: bool):
-        raise NotImplementedError('`output_onehot_size` (Annoy + DBSCAN vocabulary quantisation, reference :916-1007) is '
-                                  'outside the accelerated hot path and its dependencies are not available offline.')
+        """`output_onehot_size`: merge near-duplicate words of the target vocabulary into clusters (reference :916-1007).
+
+        The reference builds an Annoy index (angular metric) over the unit word vectors, takes every word's
+        n = min(3 * max(1, N // max_vocabulary_size), N - 1) nearest neighbours (itself included, distance 0) as a sparse
+        distance matrix, runs scikit-learn's DBSCAN on it (metric 'precomputed', eps = the mean of all stored distances,
+        min_samples = max(1, N // (4 * max_vocabulary_size))), turns every noise point into a cluster of its own and
+        returns (cluster id per word, L2-normalised cluster centroids).
+
+        Here the neighbours are EXACT: one fp32 MFMA GEMM of the vocabulary against itself with a fused per-row top-n
+        (`c1v_vocab_topn`, the nearest-word kernel of SURVEY.md row a10-ii), angular distance sqrt(2 - 2 cos) as Annoy
+        defines it.  Annoy is an approximate, randomly seeded index (and is not installable here), so its neighbour lists
+        -- and with them the clusters -- are not reproducible even between two runs of the reference: parity unpinned by
+        construction; exact neighbours are the limit its `search_k=-1` query approximates.  DBSCAN itself is scikit-learn's,
+        as in the reference."""
+        from scipy.sparse import csr_matrix
+        from sklearn.cluster import DBSCAN
+        from .engine import VocabTopN
+        vectors = np.ascontiguousarray(word_vectors, dtype=np.float32)
+        n_words = vectors.shape[0]
+        n_neighbours = min(3 * max(1, int(n_words // max_vocabulary_size)), n_words - 1)
+        if verbose:
+            print('')
+            print('----------------------------------------')
+            print('Calculation of neighbourhood matrix is started...')
+            print('----------------------------------------')
+        start_time = time.time()
+        score, index = VocabTopN(vectors, device=Conv1dTextVAE.device).run(vectors, n_neighbours)
+        # every word is its own nearest neighbour at distance 0 (Annoy's get_nns_by_item returns the item first); a
+        # duplicate row could tie with it, so the diagonal is written explicitly
+        rows = np.repeat(np.arange(n_words, dtype=np.int32), n_neighbours)
+        dist = np.sqrt(np.maximum(2.0 - 2.0 * score.astype(np.float64), 0.0)).astype(np.float32)
+        has_self = (index == np.arange(n_words)[:, None]).any(axis=1)
+        index[~has_self, -1] = np.nonzero(~has_self)[0]
+        dist[index == np.arange(n_words)[:, None]] = 0.0
+        if verbose:
+            print('{0:.3f} seconds:\t100% of vectors has been processed...'.format(time.time() - start_time))
+            print('Number of all elements is {0}.'.format(n_words * n_words))
+            print('Part of nonzero elements is {0:.3%}.'.format(dist.size / float(n_words * n_words)))
+        neighbourhood = csr_matrix((dist.reshape(-1), (rows, index.reshape(-1).astype(np.int32))), shape=(n_words, n_words))
+        clustering = DBSCAN(n_jobs=1, min_samples=max(1, int(n_words // (max_vocabulary_size * 4))), metric='precomputed',
+                            eps=float(np.mean(dist)))
+        if verbose:
+            print('')
+            print('----------------------------------------')
+            print('DBSCAN clustering with scikit-learn is started...')
+            print('----------------------------------------')
+            print('n_samples = {0}'.format(n_words))
+            print('DBSCAN.min_samples = {0}'.format(clustering.min_samples))
+            print('DBSCAN.eps = {0}'.format(clustering.eps))
+        labels = clustering.fit_predict(neighbourhood)
+        n_clusters = len(set(labels.tolist()) - {-1})
+        noise = labels < 0
+        # noise points become clusters of their own, numbered after the "good" ones in word order
+        word_clusters = np.where(noise, n_clusters + np.cumsum(noise) - 1, labels).astype(np.int64)
+        n_all = n_clusters + int(noise.sum())
+        if verbose:
+            print('DBSCAN training is finished...')
+            print('Number of "good" clusters is {0}.'.format(n_clusters))
+            print('Number of all clusters (including noisy data) is {0}.'.format(n_all))
+            print('')
+            print('Quantization with DBSCAN is started...')
+        centers = np.zeros((n_all, vectors.shape[1]), dtype=np.float32)
+        np.add.at(centers, word_clusters, vectors)
+        centers /= np.bincount(word_clusters, minlength=n_all).astype(np.float32)[:, None]
+        centers /= np.linalg.norm(centers, axis=1, keepdims=True)
+        if verbose:
+            print('Quantization with DBSCAN is finished...')
+            print('')
+        return [int(c) for c in word_clusters], centers
 
     @staticmethod
     def get_vocabulary_and_word_vectors_from_fasttext(all_texts, fasttext_vectors, special_symbols,

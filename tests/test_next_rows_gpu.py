@@ -195,3 +195,80 @@ def test_greedy_decode_on_the_gpu_equals_the_reference_character_loop():
         hits = np.nonzero(row == eos)[0]
         n = int(hits[0]) + 1 if hits.size else row.shape[0]
         assert list(row[:n]) == out[b]
+
+
+# ------------------------------------------------------------------------------------------------ f4: vocabulary quantiser
+def _planted_vectors(rng, n_clusters=25, per=16, n_lonely=30, dim=48, spread=0.03):
+    centres = rng.standard_normal((n_clusters, dim))
+    centres /= np.linalg.norm(centres, axis=1, keepdims=True)
+    rows, owner = [], []
+    for c in range(n_clusters):
+        rows.append(centres[c] + spread * rng.standard_normal((per, dim)))
+        owner += [c] * per
+    lonely = rng.standard_normal((n_lonely, dim))
+    rows.append(lonely)
+    owner += list(range(n_clusters, n_clusters + n_lonely))
+    v = np.concatenate(rows).astype(np.float32)
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    perm = rng.permutation(v.shape[0])
+    return v[perm], np.asarray(owner)[perm]
+
+
+def test_quantize_word_vectors_matches_an_exact_knn_dbscan_restatement():
+    """`output_onehot_size` (reference :916-1007): the GPU neighbour search + scikit-learn DBSCAN against the same
+    pipeline with the neighbours taken from a float64 NumPy distance matrix; planted clusters come out as clusters."""
+    from scipy.sparse import csr_matrix
+    from sklearn.cluster import DBSCAN
+    from conv1d_text_vae_amd import Conv1dTextVAE
+    rng = np.random.RandomState(11)
+    v, owner = _planted_vectors(rng)
+    n = v.shape[0]
+    max_vocab = 60
+    clusters, centers = Conv1dTextVAE.quantize_word_vectors(v, max_vocab, verbose=False)
+    assert isinstance(clusters, list) and len(clusters) == n and centers.dtype == np.float32
+    assert centers.shape == (max(clusters) + 1, v.shape[1])
+    np.testing.assert_allclose(np.linalg.norm(centers, axis=1), 1.0, atol=1e-5)
+    # restatement: exact neighbours from float64 cosines
+    k = min(3 * max(1, n // max_vocab), n - 1)
+    cos = v.astype(np.float64) @ v.astype(np.float64).T
+    np.fill_diagonal(cos, 2.0)                                           # the word itself first
+    nb = np.argsort(-cos, axis=1, kind='stable')[:, :k]
+    d = np.sqrt(np.maximum(2.0 - 2.0 * np.take_along_axis(np.minimum(cos, 1.0), nb, axis=1), 0.0))
+    d[:, 0] = 0.0
+    m = csr_matrix((d.reshape(-1).astype(np.float32), (np.repeat(np.arange(n), k), nb.reshape(-1))), shape=(n, n))
+    ref = DBSCAN(n_jobs=1, min_samples=max(1, n // (max_vocab * 4)), metric='precomputed', eps=float(np.mean(d.astype(np.float32)))).fit_predict(m)
+    n_good = len(set(ref.tolist()) - {-1})
+    noise = ref < 0
+    want = np.where(noise, n_good + np.cumsum(noise) - 1, ref)
+    assert clusters == [int(c) for c in want]
+    # planted structure: the members of a planted cluster share one id, different planted clusters do not
+    got = np.asarray(clusters)
+    for c in range(25):
+        ids = set(got[owner == c].tolist())
+        assert len(ids) == 1, (c, ids)
+    assert len(set(got[owner < 25].tolist())) == 25
+    # centroid of a planted cluster = normalised mean of its members
+    c0 = got[owner == 0][0]
+    mean = v[owner == 0].mean(axis=0)
+    np.testing.assert_allclose(centers[c0], mean / np.linalg.norm(mean), atol=1e-5)
+
+
+def test_output_onehot_size_shrinks_the_target_vocabulary():
+    """prepare_vocabulary_and_word_vectors with max_vocabulary_size (reference :1035-1039): words of one cluster share a
+    row of the (smaller) vocabulary matrix; flag rows and the end-of-sentence row keep their places behind the clusters."""
+    from conv1d_text_vae_amd import Conv1dTextVAE
+    from conv1d_text_vae_amd import embeddings as E
+    rng = np.random.RandomState(5)
+    v, owner = _planted_vectors(rng, n_clusters=12, per=10, n_lonely=8, dim=32)
+    words = ['w%d' % i for i in range(v.shape[0])]
+    kv = E.FastTextKeyedVectors(32, 0, 0, 0)
+    kv.add(words, v)
+    texts = tuple(tuple(words[i:i + 7]) for i in range(0, len(words), 7))
+    full_vocab, full_mat = Conv1dTextVAE.prepare_vocabulary_and_word_vectors(texts, kv, None)
+    vocab, mat = Conv1dTextVAE.prepare_vocabulary_and_word_vectors(texts, kv, None, 30, False)
+    assert full_mat.shape[0] == len(words) + 2 and mat.shape[0] < full_mat.shape[0] and mat.shape[1] == 34
+    assert vocab[''] == mat.shape[0] - 1 and mat[-1, -1] == 1.0 and mat[-2, 32] == 1.0
+    np.testing.assert_allclose(np.linalg.norm(mat, axis=1), 1.0, atol=1e-5)
+    for c in range(12):
+        rows = set(vocab[words[i]] for i in np.nonzero(owner == c)[0])
+        assert len(rows) == 1
