@@ -48,6 +48,7 @@ CONFIGS = {
 CFG_PREDICT = dict(batch=8192, seq_len=64, emb=300, n_filters=(128,), kernel_size=3, latent=256, vocab_words=200000)
 # BASELINE.json configs[4]: 2M-word vocabulary over 8 GPUs = 250000 rows per GPU, batch 512, seq_len 256
 CFG_PREDICT_C5 = dict(batch=512, seq_len=256, emb=300, n_filters=(128,), kernel_size=3, latent=256, words_per_gpu=250000)
+DENSE_INPUT = os.environ.get('C1V_BENCH_DENSE_INPUT', '0') == '1'     # A/B: the round-1 form of the timed input
 BF16_DENSE_PEAK_TFLOPS = 2500.0       # /opt/skills/guides/MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
 F32_MATRIX_PEAK_TFLOPS = 157.3        # same guide: fp32 MFMA
 
@@ -163,9 +164,17 @@ def make_train_engine(cfg, dtype, dev, world, rank, force_dp):
     W = synthetic.synthetic_vocab(cfg['vocab_rows'] - 2, cfg['emb'])
     B = cfg['batch']
     # every rank draws its own slice of the global batch (seed keyed by the rank)
-    x, ids = synthetic.synthetic_batch(W, W.shape[0], B, cfg['seq_len'], cfg['seq_len'], seed=1234 + 7919 * rank)
+    x, ids, in_ids = synthetic.synthetic_batch(W, W.shape[0], B, cfg['seq_len'], cfg['seq_len'], seed=1234 + 7919 * rank,
+                                               with_input_ids=True)
     eng = engine.VAEEngine(g, B, W, dtype=dtype, device=dev, seed=1234, world_size=world, rank=rank, force_bucketed=force_dp)
-    eng.load_batch(x, ids)      # inputs resident in HBM
+    # inputs resident in HBM, in the form fit() hands them over (estimator.py: set_input_table + in_ids, reference
+    # SequenceForVAE.__getitem__ :1374-1390 on the device): the word-vector table and one row id per step; DENSE_INPUT=1
+    # feeds the assembled fp32 [B, T, V] batch instead
+    eng.load_batch(x if DENSE_INPUT else None, ids)
+    if not DENSE_INPUT:
+        import torch
+        eng.set_input_table(W)
+        eng.in_ids.copy_(torch.from_numpy(in_ids))
     return eng, g, W, ids
 
 
@@ -216,18 +225,18 @@ def train_leg(cfg_name, dtype, dev, world, rank, steps, warmup, dist=None, force
             torch.cuda.synchronize()
 
     if kernel_only:
-        eng.train_step(use_graph=False)
+        eng.train_step(use_graph=False, from_ids=not DENSE_INPUT)
         for _ in range(steps):
             eng.op_xent_accum()
         torch.cuda.synchronize()
         return None
 
     for _ in range(max(warmup, 2)):
-        eng.train_step(all_reduce=all_reduce)
+        eng.train_step(all_reduce=all_reduce, from_ids=not DENSE_INPUT)
     sync()
     t0 = time.perf_counter()
     for _ in range(steps):
-        eng.train_step(all_reduce=all_reduce)
+        eng.train_step(all_reduce=all_reduce, from_ids=not DENSE_INPUT)
     sync()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -253,6 +262,8 @@ def train_leg(cfg_name, dtype, dev, world, rank, steps, warmup, dist=None, force
             'value': B * world * steps / elapsed, 'unit': 'sequences/s', 'ms_per_step': elapsed / steps * 1e3, 'steps': steps,
             'config': {'workload': cfg['text'], 'global_batch': B * world, 'per_gpu_batch': B, 'seq_len': cfg['seq_len'],
                        'vocab_rows': int(W.shape[0]), 'parallelism': 'dp%d' % world,
+                       'input': 'dense fp32 [B, T, V] batch' if DENSE_INPUT else
+                                'word-vector table + int32 row ids [B, T] (c1v_gather_input, as fit() feeds the engine)',
                        'step_gflop_dense': (model_flops + loss_flops) / 1e9,
                        'step_gflop_live': (model_flops + loss_live) / 1e9, 'final_loss': loss,
                        'grad_allreduce_bytes': int(eng.P) * 4 if world > 1 or force_dp else 0},

@@ -110,7 +110,7 @@ class XentAccumArgs(C.Structure):
     _fields_ = [('yhat', C.c_void_p), ('dtype', C.c_int32), ('M', C.c_int32), ('kp', C.c_int32), ('w', C.c_void_p),
                 ('N', C.c_int32), ('n_pad', C.c_int32), ('ut', C.c_void_p), ('m_pad', C.c_int32),
                 ('splits', C.c_int32), ('need_u', C.c_int32), ('ones_col', C.c_int32), ('logits', C.c_void_p),
-                ('n_chunk', C.c_int32), ('live_ctl', C.c_void_p)]
+                ('n_chunk', C.c_int32), ('live_ctl', C.c_void_p), ('ut_dtype', C.c_int32)]
 
 
 class XentFinishArgs(C.Structure):
@@ -118,7 +118,8 @@ class XentFinishArgs(C.Structure):
                 ('ones_col', C.c_int32), ('yhat', C.c_void_p), ('w', C.c_void_p), ('dtype', C.c_int32),
                 ('rnorm', C.c_void_p), ('qscale', C.c_float), ('ids', C.c_void_p), ('B', C.c_int32), ('T', C.c_int32),
                 ('V', C.c_int32), ('B_global', C.c_int32), ('xent_rows', C.c_void_p), ('xent_b', C.c_void_p),
-                ('dy', Seq), ('y', C.c_void_p), ('ldy', C.c_int64), ('pos', C.c_void_p), ('live_ctl', C.c_void_p)]
+                ('dy', Seq), ('y', C.c_void_p), ('ldy', C.c_int64), ('pos', C.c_void_p), ('live_ctl', C.c_void_p),
+                ('ut_dtype', C.c_int32)]
 
 
 class SegDesc(C.Structure):
@@ -219,6 +220,8 @@ SYMBOLS = {
     'c1v_sqnorm_partial': ([C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p], C.c_int),
     'c1v_nadam_step': ([_P(NadamArgs), C.c_void_p], C.c_int),
     'c1v_nadam_advance': ([C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p], C.c_int),
+    'c1v_eos_truncate_normalize_ld': ([C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p],
+                                      C.c_int),
     'c1v_eos_truncate_normalize': ([C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p],
                                    C.c_int),
     'c1v_eos_truncate_normalize_f64': ([C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,

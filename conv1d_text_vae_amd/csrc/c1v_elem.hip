@@ -547,18 +547,18 @@ extern "C" int c1v_nadam_step(const c1v_nadam_args* a, void* stream) {
 // EOS truncation + renormalisation (reference :542-565): one wave per sample
 // ------------------------------------------------------------------------------------------------------
 template <typename F>
-__global__ __launch_bounds__(256) void eos_truncate_kernel(const F* __restrict__ y, int B, int T_len, int V,
+__global__ __launch_bounds__(256) void eos_truncate_kernel(const F* __restrict__ y, int64_t ldy, int B, int T_len, int V,
                                                            F* __restrict__ out, int* __restrict__ end_idx) {
     const int lane = threadIdx.x & 63;
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (b >= B) return;
-    const F* yb = y + (int64_t)b * T_len * V;
+    const F* yb = y + (int64_t)b * T_len * ldy;             // rows of V values, ldy apart
     F* ob = out + (int64_t)b * T_len * (V - 1);
     int end = T_len;
     for (int t = 0; t < T_len; ++t) {
         // np.argmax: first maximum wins
         F best = sizeof(F) == 8 ? (F)-1.7e308 : (F)-3.0e38; int bi = 0x7fffffff;
-        for (int c = lane; c < V; c += 64) { const F v = yb[(int64_t)t * V + c]; if (v > best) { best = v; bi = c; } }
+        for (int c = lane; c < V; c += 64) { const F v = yb[(int64_t)t * ldy + c]; if (v > best) { best = v; bi = c; } }
         for (int o = 32; o > 0; o >>= 1) {
             const F ov = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64);
             if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
@@ -569,27 +569,31 @@ __global__ __launch_bounds__(256) void eos_truncate_kernel(const F* __restrict__
     for (int t = 0; t < T_len; ++t) {
         if (t < end) {
             F ss = (F)0;
-            for (int c = lane; c < V - 1; c += 64) { const F v = yb[(int64_t)t * V + c]; ss += v * v; }
+            for (int c = lane; c < V - 1; c += 64) { const F v = yb[(int64_t)t * ldy + c]; ss += v * v; }
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
             const F nrm = sqrt(ss);
-            for (int c = lane; c < V - 1; c += 64) ob[(int64_t)t * (V - 1) + c] = yb[(int64_t)t * V + c] / nrm;
+            for (int c = lane; c < V - 1; c += 64) ob[(int64_t)t * (V - 1) + c] = yb[(int64_t)t * ldy + c] / nrm;
         } else {
             for (int c = lane; c < V - 1; c += 64) ob[(int64_t)t * (V - 1) + c] = (F)0;
         }
     }
 }
-extern "C" int c1v_eos_truncate_normalize(const float* y, int32_t B, int32_t T, int32_t V, float* out, int32_t* end_idx, void* stream) {
+extern "C" int c1v_eos_truncate_normalize_ld(const float* y, int64_t ldy, int32_t B, int32_t T, int32_t V, float* out, int32_t* end_idx,
+                                             void* stream) {
     C1V_REQUIRE(y && out, "eos_truncate_normalize: null argument");
-    C1V_REQUIRE(B > 0 && T > 0 && V > 1, "eos_truncate_normalize: bad shape");
-    hipLaunchKernelGGL(eos_truncate_kernel<float>, dim3((unsigned)c1v_cdiv(B, 4)), dim3(256), 0, (hipStream_t)stream, y, B, T, V, out, end_idx);
+    C1V_REQUIRE(B > 0 && T > 0 && V > 1 && ldy >= V, "eos_truncate_normalize: bad shape (B=%d T=%d V=%d ldy=%lld)", B, T, V, (long long)ldy);
+    hipLaunchKernelGGL(eos_truncate_kernel<float>, dim3((unsigned)c1v_cdiv(B, 4)), dim3(256), 0, (hipStream_t)stream, y, ldy, B, T, V, out, end_idx);
     C1V_LAUNCH_CHECK();
     return 0;
+}
+extern "C" int c1v_eos_truncate_normalize(const float* y, int32_t B, int32_t T, int32_t V, float* out, int32_t* end_idx, void* stream) {
+    return c1v_eos_truncate_normalize_ld(y, V, B, T, V, out, end_idx, stream);
 }
 extern "C" int c1v_eos_truncate_normalize_f64(const double* y, int32_t B, int32_t T, int32_t V, double* out, int32_t* end_idx, void* stream) {
     C1V_REQUIRE(y && out, "eos_truncate_normalize_f64: null argument");
     C1V_REQUIRE(B > 0 && T > 0 && V > 1, "eos_truncate_normalize_f64: bad shape");
-    hipLaunchKernelGGL(eos_truncate_kernel<double>, dim3((unsigned)c1v_cdiv(B, 4)), dim3(256), 0, (hipStream_t)stream, y, B, T, V, out, end_idx);
+    hipLaunchKernelGGL(eos_truncate_kernel<double>, dim3((unsigned)c1v_cdiv(B, 4)), dim3(256), 0, (hipStream_t)stream, y, (int64_t)V, B, T, V, out, end_idx);
     C1V_LAUNCH_CHECK();
     return 0;
 }

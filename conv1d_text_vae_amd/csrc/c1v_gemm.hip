@@ -12,7 +12,9 @@ __global__ __launch_bounds__(C1V_GEMM_THREADS) void gemm_nt_kernel(const NtParam
 template <typename T, int NS>
 __global__ __launch_bounds__(C1V_GEMM_THREADS, 3) void gemm_nt_large_kernel(const NtParams p) {
     c1v_touch_kernarg<4>();
-    nt_body<T, 128, 128, NS, false>(p, blockIdx.x, blockIdx.y, blockIdx.x + gridDim.x * blockIdx.y, 0);
+    int bx, by;
+    xcd_tile(blockIdx.x, (p.e.M + 127) >> 7, (p.e.N + 127) >> 7, bx, by);
+    nt_body<T, 128, 128, NS, false>(p, bx, by, blockIdx.x, 0);
 }
 template <typename T>
 __global__ __launch_bounds__(C1V_GEMM_THREADS) void gemm_tn_kernel(const TnParams p) {
@@ -32,8 +34,8 @@ template <typename T, int BM, int BN, int NS> static void launch_nt_v(const NtPa
 template <typename T, int NS> static void launch_nt_large_ns(const NtParams& p, hipStream_t st) {
     constexpr int LDS = nt_lds<128, 128, NS>();
     static bool once = (set_lds(gemm_nt_large_kernel<T, NS>, LDS), true); (void)once;
-    // M tiles fastest: the workgroups that run together share the weight tile and stream the activations
-    dim3 grid((unsigned)c1v_cdiv(p.e.M, 128), (unsigned)c1v_cdiv(p.e.N, 128), 1);
+    // a linear grid, dealt to (row tile, column tile) by xcd_tile()
+    dim3 grid((unsigned)(c1v_cdiv(p.e.M, 128) * c1v_cdiv(p.e.N, 128)), 1, 1);
     hipLaunchKernelGGL((gemm_nt_large_kernel<T, NS>), grid, dim3(C1V_GEMM_THREADS), LDS, st, p);
 }
 template <typename T> static void launch_nt_large(const NtParams& p, hipStream_t st) {

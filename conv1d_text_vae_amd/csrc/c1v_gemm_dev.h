@@ -494,6 +494,17 @@ constexpr int C1V_GEMM_THREADS = 384;
 // behind it).  The large-GEMM variant (PRE = false) asks for them after the K loop instead: they would pin ~66 registers
 // through it, and that variant runs TWO workgroups per CU (<= 168 registers), where the other workgroup's K loop hides
 // this one's epilogue.
+// XCD-aware deal of a large GEMM's output tiles.  Workgroups go to the 8 XCDs round-robin in dispatch order and every XCD
+// has an L2 of its own; with row tiles fastest in the grid the column tiles of one row tile ran thousands of workgroups
+// apart, so every column tile fetched its activation rows from HBM again (2-4x the operand at 256-512 output channels).
+// Here XCD k (= id % 8) owns a CONTIGUOUS range of the tiles in (row tile, column tile) order, column tile fastest: the
+// workgroups that share an activation row tile are dispatched back to back to the same XCD and share its L2 copy.
+__device__ __forceinline__ void xcd_tile(int id, int gm, int gn, int& bx, int& by) {
+    const int total = gm * gn, k = id & 7, j = id >> 3;
+    const int w = k * (total >> 3) + (k < (total & 7) ? k : (total & 7)) + j;
+    bx = w / gn; by = w - bx * gn;
+}
+
 template <typename T, int BM, int BN, int NS, bool PRE = true>
 __device__ __forceinline__ void nt_body(const NtParams& p, const int bx, const int by, const int wg_linear, const int ks = 0) {
 #ifdef NT_STAMP

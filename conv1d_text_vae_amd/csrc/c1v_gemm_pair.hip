@@ -37,8 +37,10 @@ __global__ __launch_bounds__(C1V_GEMM_THREADS, 3) void gemm_pair_large_kernel(co
         const int by = r / pp.tn_gi, bx = r - by * pp.tn_gi;
         tn_body<T>(pp.tn, bx, by, bz);
     } else {
+        // (r % 8 names the XCD as well as id % 8 does: the same shift for every workgroup)
         const int r = id - pp.tn_blocks;
-        const int by = r / pp.nt_gm, bx = r - by * pp.nt_gm;
+        int bx, by;
+        xcd_tile(r, pp.nt_gm, (pp.nt.e.N + 127) >> 7, bx, by);
         nt_body<T, 128, 128, NS, false>(pp.nt, bx, by, r);
     }
 }

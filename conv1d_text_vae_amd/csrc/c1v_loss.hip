@@ -70,6 +70,18 @@ __global__ __launch_bounds__(1024) void live_rows_kernel(const int* __restrict__
 // fused vocabulary stream kernel (bf16)
 // ------------------------------------------------------------------------------------------------------
 enum { VS_ACCUM = 0, VS_SUMEXP = 1, VS_ARGMAX = 2 };
+// Two round-2 variants of the ACCUM tile, both parity-green, both measured at C2 and C4 and neither faster than the plain
+// form (47.2-48.8 us at C2 either way; stamps in DESIGN.md section 5), kept as diagnostic builds:
+//   -DVS_INTERLEAVE=1  block 1's exp2 / bf16 conversion rides in the MFMA gaps of GEMM2 on block 0 (one v_exp_f32 or two
+//                      v_cvt_pk per gap, which profiles/microbench/mfma_chain.hip shows to be free next to a 32-cycle MFMA)
+//   -DVS_REGFEED=1|2   the LDS ring is fed through registers (buffer_load_dwordx4 + ds_write_b128, one piece per MFMA gap)
+//                      instead of LDS-DMA requests; 2 = the reload follows the ds_write at once (a whole tile to arrive)
+#ifndef VS_INTERLEAVE
+#define VS_INTERLEAVE 0
+#endif
+#ifndef VS_REGFEED
+#define VS_REGFEED 0
+#endif
 #ifdef VS_STAMP
 // diagnostic build only: per-segment cycle sums of wave 0 of every workgroup (guide: "In-kernel stamps")
 __device__ unsigned long long vs_dbg[8 * 4096];
@@ -106,7 +118,7 @@ template <int CB> __device__ __forceinline__ int vs_off(int r, int ch) { return 
 template <int CB, int MODE, int MB>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void vocab_stream_kernel(const bf16_raw* __restrict__ yhat, int M, const bf16_raw* __restrict__ w, int N, int n_base,
-                         int tiles_total, int tiles_per_split, float* __restrict__ ut, int m_pad, int ones_col,
+                         int tiles_total, int tiles_per_split, float* __restrict__ ut, int ut_bf16, int m_pad, int ones_col,
                          float* __restrict__ part_score, int* __restrict__ part_idx, const int* __restrict__ ctl) {
     using Cfg = VsCfg<CB>;
     constexpr int KS = CB * 2;                     // 16-wide k steps of GEMM1
@@ -126,6 +138,9 @@ void vocab_stream_kernel(const bf16_raw* __restrict__ yhat, int M, const bf16_ra
     int bx = blockIdx.x, split = blockIdx.y;       // row tile, vocabulary split
     if (ctl) {
         // compacted rows (live_rows_kernel): the grid is a pool of workgroups, dealt to (row tile, split) on the device
+        // (A split-major deal that keeps the workgroups of one XCD on one or two vocabulary splits -- so that each L2 fetches
+        // 2/splits of W instead of all of it -- was measured at C2: 1 % SLOWER, 49.0 against 48.5 us; W is L2/MALL-resident
+        // either way and 32 CUs asking for the same lines at the same time is worse than 5 of them.)
         const int live = ctl[0], splits = ctl[2];
         const int item = blockIdx.x + gridDim.x * blockIdx.y;
         bx = item / splits; split = item - bx * splits;
@@ -159,8 +174,27 @@ void vocab_stream_kernel(const bf16_raw* __restrict__ yhat, int M, const bf16_ra
 
     // three LDS stages: tile t+2 is requested when tile t starts, so a request has two tile times to arrive (with two
     // stages the L2/fabric latency of a 44 KiB request, not the MFMA work, set the tile time)
+    // ACCUM feeds the ring through REGISTERS instead (REGFEED): an LDS-DMA request costs the issuing wave 60-100 cycles
+    // wherever it is placed (one per MFMA gap was measured too: slower than the burst), and with one wave per SIMD and no
+    // registers for a feeder wave that was ~20 % of the tile.  A plain global_load_dwordx4 and, one tile later, a
+    // ds_write_b128 per piece issue in the shadow of the MFMAs: piece i of tile t+2 is loaded behind MFMA i of GEMM2(t)
+    // and written to its stage behind one of the last MFMAs of GEMM1(t+1), in front of the barrier that publishes it.
+    constexpr bool REGFEED = MODE == VS_ACCUM && VS_REGFEED != 0;
+    typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));          // (a plain vector: no aggregate copies)
+    u32x4_t R[REGFEED ? Cfg::PPW : 1];
+    // (macros, not lambdas: behind a second level of closures the array stayed in scratch memory)
+    // (buffer loads: SGPR descriptor + SGPR tile offset + the lane's 32-bit offset -- no 64-bit address arithmetic per piece)
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, 0x7fffffff, 0x00020000);
+#define VS_LOAD_PIECE(tb_, i_) R[i_] = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, src_off[i_], (tb_), 0)
+    auto tile_base = [&](int t) -> int { return __builtin_amdgcn_readfirstlane(t * (VS_BN * Cfg::ROWB)); };   // bytes, < 2^31 (host check)
+#define VS_WRITE_PIECE(stage_, i_) *(u32x4_t*)(smem + (stage_) * Cfg::STAGE + (wave + 4 * (i_)) * 1024 + lane * 16) = R[i_]
     if (t_begin < t_end) stage_tile(t_begin, 0);
-    if (t_begin + 1 < t_end) stage_tile(t_begin + 1, 1);
+    if constexpr (REGFEED) {
+#pragma unroll
+        for (int i = 0; i < Cfg::PPW; ++i) VS_LOAD_PIECE(tile_base(t_begin + 1 < t_end ? t_begin + 1 : t_end - 1), i);
+    } else {
+        if (t_begin + 1 < t_end) stage_tile(t_begin + 1, 1);
+    }
 
     // this wave's 32 sample rows as MFMA B operands: B[k = 8h + j][col = l31] = yhat[m_row][16 s + 8h + j]
     bf16x8_t yf[MB][KS];
@@ -200,9 +234,10 @@ void vocab_stream_kernel(const bf16_raw* __restrict__ yhat, int M, const bf16_ra
     // (the compiler otherwise re-serialises every ds_read behind an lgkmcnt(0) in front of its MFMA, which tripled the
     // tile time).
     // GEMM1 batch: KB k-steps of BOTH 32-row blocks of the tile, issued alternately -- consecutive MFMAs never accumulate
-    // into the same registers.  Measured on gfx950 (scratch micro-benchmark): a chain of dependent 32x32x16 MFMAs runs at
-    // 55 cycles each, two or more independent chains at 37; and VALU instructions issued between MFMAs do NOT hide behind
-    // them (each costs ~3 cycles of MFMA throughput), so the VALU stages simply follow GEMM1.
+    // into the same registers.  Measured on gfx950 (profiles/microbench/mfma_chain.hip, s_memtime cycles): a chain of dependent
+    // 32x32x16 MFMAs issues every 44 cycles, two or more independent chains every 32; behind each MFMA the wave may issue 8 cycles
+    // of VALU work for free (one v_exp_f32, or two v_fma / v_cvt_pk), anything more delays the next MFMA cycle for cycle -- with
+    // one or two waves per SIMD alike.  The VALU stages simply follow GEMM1 (see VS_INTERLEAVE above for the measured alternative).
     constexpr int KB = 2, G1 = 2 * KB;                  // k-steps / fragments per batch
     constexpr int Q1 = KS / KB, HB = (Q1 + 1) / 2;      // batches; the GEMM1-only modes put their barrier behind batch HB-1
     static_assert(KS % KB == 0, "k-steps come in pairs");
@@ -238,7 +273,11 @@ void vocab_stream_kernel(const bf16_raw* __restrict__ yhat, int M, const bf16_ra
     const int g2off_lo = vs_off<CB>(4 * h + tq, 2 * tcg + (tpq >> 1)) + 8 * (tpq & 1);
     const int g2off_hi = vs_off<CB>(4 * h + tq + 8, 2 * tcg + (tpq >> 1)) + 8 * (tpq & 1);
     auto ld1_at = [&](const char* base, int nb, int s) -> uint4 {
+#if defined(VS_ABLATE) && (VS_ABLATE & 32)
+        return make_uint4(lane + s, nb, 0x3f803f80u, 0x3f803f80u);          // diagnostic: GEMM1 without its LDS reads
+#else
         return *(const uint4*)(base + g1off[s & 1] + nb * 32 * Cfg::PITCH + (s >> 1) * 64);
+#endif
     };
     uint4 a1[2][G1];
     if (t_begin < t_end) {
@@ -301,11 +340,15 @@ void vocab_stream_kernel(const bf16_raw* __restrict__ yhat, int M, const bf16_ra
         const char* sw = smem + stage * Cfg::STAGE;
 #endif
         const int n0 = t * VS_BN;
+        const int tb2 = REGFEED ? tile_base(t + 2 < t_end ? t + 2 : t_end - 1) : 0;
 
         auto ld1 = [&](int nb, int s) -> uint4 { return ld1_at(sw, nb, s); };
         // W^T fragment of GEMM2: k slot (h, j) of step (nb, ks) is vocabulary row nb*32 + 16ks + 8(j>>2) + 4h + (j&3),
         // exactly the accumulator rows held in regs 8ks..8ks+7 of S[nb]
         auto ld2 = [&](int nb, int ks, int cb) -> uint4 {
+#if defined(VS_ABLATE) && (VS_ABLATE & 16)
+            return make_uint4(lane + ks, nb + cb, 0x3f803f80u, 0x3f803f80u);     // diagnostic: GEMM2 without its LDS reads
+#endif
             const int imm = (nb * 32 + 16 * ks) * Cfg::PITCH + cb * 64;
             s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(C1V_LDS_PTR(s16x4_t, sw + g2off_lo + imm));
             s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(C1V_LDS_PTR(s16x4_t, sw + g2off_hi + imm));
@@ -346,6 +389,17 @@ void vocab_stream_kernel(const bf16_raw* __restrict__ yhat, int M, const bf16_ra
                         S[mb][f & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a1[q & 1][f]), yf[mb][s0 + (f >> 1)],
                                                                                (q == 0 && f < 2) ? zero16 : S[mb][f & 1], 0, 0, 0);
                 }
+                if constexpr (REGFEED) {
+                    // tile t+1 from registers to its stage (dead since the barrier of tile t-1), one piece per gap, behind the last
+                    // PPW MFMAs of GEMM1 (on the last tile this writes a stale copy into a dead stage: no branch)
+                    constexpr int G0 = Q1 * G1 - Cfg::PPW;
+                    const int g = q * G1 + f;
+                    if (g >= G0) {
+                        VS_WRITE_PIECE((stage + 1) % VS_STAGES, g - G0);
+                        if (VS_REGFEED == 2) VS_LOAD_PIECE(tb2, g - G0);      // reload at once: a whole tile time to arrive
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
             }
 #if !(defined(VS_ABLATE) && (VS_ABLATE & 8))
             if constexpr (MODE != VS_ACCUM) {
@@ -373,21 +427,41 @@ void vocab_stream_kernel(const bf16_raw* __restrict__ yhat, int M, const bf16_ra
             if (q == HB - 1) VS_T(0);
             if (q == Q1 - 1) VS_T(1);
         }
-        // VALU stage on both blocks
+        // VALU stage (VS_INTERLEAVE builds: block 0 only, block 1 rides in the MFMA gaps of GEMM2 on block 0)
         post(S, 0, 0, 16, n0, 0, MB, tailc);
-        post(S, 1, 0, 16, n0, 0, MB, tailc);
+        if constexpr (MODE != VS_ACCUM || VS_INTERLEAVE == 0) post(S, 1, 0, 16, n0, 0, MB, tailc);
 
         if constexpr (MODE == VS_ACCUM) {
             bf16x8_t pf[2][2];
 #pragma unroll
-            for (int nb = 0; nb < 2; ++nb)
+            for (int nb = 0; nb < (VS_INTERLEAVE ? 1 : 2); ++nb)
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
                     for (int j = 0; j < 8; ++j) pf[nb][ks][j] = (__bf16)S[0][nb][8 * ks + j];
+            // block 1 in 20 units of <= 8 issue cycles: units 0..15 = exp2 of accumulator register u, units 16..19 = conversion
+            // of four values to bf16; GEMM2 on block 0 has 2 CB gaps, gap g takes units [g UPG, (g+1) UPG)
+            // (asm volatile: as builtins the compiler sinks all of it to the block of first use, behind the last batch)
+            constexpr int UPG = (20 + 2 * CB - 1) / (2 * CB);
+            uint32_t pk1[8];
+            auto gap_units = [&](int g) {
+#pragma unroll
+                for (int u = g * UPG; u < (g + 1) * UPG && u < 20; ++u) {
+                    if (u < 16) {
+                        asm volatile("v_exp_f32 %0, %0" : "+v"(S[0][1][u]));
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            const int r = 4 * (u - 16) + 2 * e;
+                            asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pk1[r >> 1]) : "v"(S[0][1][r]), "v"(S[0][1][r + 1]));
+                        }
+                    }
+                }
+            };
 #if !(defined(VS_ABLATE) && (VS_ABLATE & 8))
             // the tile's only barrier: tile t+1 (this wave's pieces: everything it has in flight) is in LDS, tile t-1 is dead
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // (register feed: the pieces went to LDS with ds_write, which the barrier's fence waits for)
+            if constexpr (!REGFEED) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             VS_T(4);
             __syncthreads();
             VS_T(5);
@@ -408,15 +482,35 @@ void vocab_stream_kernel(const bf16_raw* __restrict__ yhat, int M, const bf16_ra
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-                    for (int c = 0; c < CG; ++c)
+                    for (int c = 0; c < CG; ++c) {
 #if defined(VS_ABLATE) && (VS_ABLATE & 2)
                         if (cb0 + c == 0)
 #endif
                         U[cb0 + c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a2[q % 3][c * 2 + ks]), pf[nb][ks],
                                                                              U[cb0 + c], 0, 0, 0);
+                        if constexpr (VS_INTERLEAVE != 0) {
+                            if (nb == 0) {                       // (compile-time: q is an unrolled index)
+                                gap_units((q % NB2) * 2 * CG + ks * CG + c);
+                                if (q == NB2 - 1 && ks == 1 && c == CG - 1) {
+                                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                                    for (int k2 = 0; k2 < 2; ++k2)
+                                        pf[1][k2] = __builtin_bit_cast(bf16x8_t, make_uint4(pk1[4 * k2], pk1[4 * k2 + 1], pk1[4 * k2 + 2], pk1[4 * k2 + 3]));
+                                }
+                            }
+                        }
+#if !(defined(VS_ABLATE) && (VS_ABLATE & 8))
+                        if constexpr (REGFEED) {
+                            // tile t+2 (clamped into the split: no branch) -> registers, one piece per MFMA gap
+                            const int g = q * 2 * CG + ks * CG + c;
+                            if (VS_REGFEED == 1 && g < Cfg::PPW) VS_LOAD_PIECE(tb2, g);
+                        }
+#endif
+                        if constexpr (VS_INTERLEAVE != 0 || REGFEED) __builtin_amdgcn_sched_barrier(0);
+                    }
 #if !(defined(VS_ABLATE) && (VS_ABLATE & 8))
                 // request for tile t+2: every wave sends all its pieces behind one batch, a different batch per wave
-                if ((Q2 >= 8 ? q == 2 * wave : q == 0) && more) {
+                if (!REGFEED && (Q2 >= 8 ? q == 2 * wave : q == 0) && more) {
 #pragma unroll
                     for (int i = 0; i < Cfg::PPW; ++i) stage_piece(t + 2, (stage + 2) % VS_STAGES, i);
                 }
@@ -449,7 +543,9 @@ void vocab_stream_kernel(const bf16_raw* __restrict__ yhat, int M, const bf16_ra
         constexpr int TP = 36;                                  // floats per transposed row (32 + 4 pad)
         __syncthreads();                                        // (slower waves may still be reading the last tile)
         float* tw = (float*)smem + wave * 32 * TP;
-        float* o = ut + ((int64_t)split * m_pad + bx * VS_BM + wave * 32) * Cfg::KP;
+        const int64_t o_row0 = ((int64_t)split * m_pad + bx * VS_BM + wave * 32) * Cfg::KP;
+        float* o = ut + o_row0;
+        bf16_raw* ob = (bf16_raw*)ut + o_row0;               // bf16 slabs (ut_bf16): half the bytes out here and into the finish step
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb) {
 #pragma unroll
@@ -459,7 +555,8 @@ void vocab_stream_kernel(const bf16_raw* __restrict__ yhat, int M, const bf16_ra
             for (int it = 0; it < 4; ++it) {
                 const int row = it * 8 + (lane >> 3), ch = lane & 7;
                 const float4 v = *(const float4*)(tw + row * TP + ch * 4);
-                *(float4*)(o + (int64_t)row * Cfg::KP + cb * 32 + ch * 4) = v;
+                if (ut_bf16) *(uint2*)(ob + (int64_t)row * Cfg::KP + cb * 32 + ch * 4) = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+                else *(float4*)(o + (int64_t)row * Cfg::KP + cb * 32 + ch * 4) = v;
             }
         }
     } else if constexpr (MODE == VS_SUMEXP) {
@@ -501,7 +598,12 @@ void vocab_stream_kernel(const bf16_raw* __restrict__ yhat, int M, const bf16_ra
 // ------------------------------------------------------------------------------------------------------
 // finish: per sample row  p_t, clip, xent, d loss / d y      (reference :1198-1203 + Keras batch mean)
 // ------------------------------------------------------------------------------------------------------
-template <typename T>
+// (UB: the `ut` slabs hold bf16 instead of fp32 -- ut_f reads element i of either)
+template <bool UB> __device__ __forceinline__ float ut_f(const float* ut, int64_t i) {
+    if constexpr (UB) return __uint_as_float((uint32_t)((const bf16_raw*)ut)[i] << 16);
+    else return ut[i];
+}
+template <typename T, bool UB>
 __global__ __launch_bounds__(256) void xent_finish_kernel(const float* __restrict__ ut, int splits, int kp, int m_pad, int ones_col,
                                                           const T* __restrict__ yhat, const T* __restrict__ w,
                                                           const float* __restrict__ rnorm, float qscale,
@@ -594,12 +696,29 @@ __global__ __launch_bounds__(256) void xent_finish_kernel(const float* __restric
         // partial sums of the vocabulary splits, four slabs (8 requests) per round, in slab order
         for (int sp0 = 0; sp0 < splits; sp0 += 4) {
             float4 v[4][NCH];
+            if constexpr (UB) {
+                uint2 r[4][NCH];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int sp = sp0 + i < splits ? sp0 + i : splits - 1;
-                const float* up = ut + ((int64_t)sp * m_pad + cr) * kp;
+                for (int i = 0; i < 4; ++i) {
+                    const int sp = sp0 + i < splits ? sp0 + i : splits - 1;
+                    const bf16_raw* up = (const bf16_raw*)ut + ((int64_t)sp * m_pad + cr) * kp;
 #pragma unroll
-                for (int q = 0; q < NCH; ++q) v[i][q] = *(const float4*)(up + cc[q]);
+                    for (int q = 0; q < NCH; ++q) r[i][q] = *(const uint2*)(up + cc[q]);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int q = 0; q < NCH; ++q)
+                        v[i][q] = make_float4(__uint_as_float(r[i][q].x << 16), __uint_as_float(r[i][q].x & 0xFFFF0000u),
+                                              __uint_as_float(r[i][q].y << 16), __uint_as_float(r[i][q].y & 0xFFFF0000u));
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int sp = sp0 + i < splits ? sp0 + i : splits - 1;
+                    const float* up = ut + ((int64_t)sp * m_pad + cr) * kp;
+#pragma unroll
+                    for (int q = 0; q < NCH; ++q) v[i][q] = *(const float4*)(up + cc[q]);
+                }
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -693,7 +812,7 @@ __global__ __launch_bounds__(256) void xent_finish_kernel(const float* __restric
     }
     float sumexp = 0.f;
 #pragma unroll 4
-    for (int sp = 0; sp < splits; ++sp) sumexp += ut[((int64_t)sp * m_pad + cr) * kp + ones_col];
+    for (int sp = 0; sp < splits; ++sp) sumexp += ut_f<UB>(ut, ((int64_t)sp * m_pad + cr) * kp + ones_col);
     float cnt = 0.f;
     for (int tt = lane; tt < T_len; tt += 64) cnt += ids[b * T_len + tt] >= 0 ? 1.f : 0.f;
     float st = 0.f;
@@ -727,11 +846,11 @@ __global__ __launch_bounds__(256) void xent_finish_kernel(const float* __restric
         for (int k = 0; k < UC; ++k) uu[k] = 0.f;
 #pragma unroll 2
         for (int sp = 0; sp < splits; ++sp) {
-            const float* up = ut + ((int64_t)sp * m_pad + cr) * kp;
+            const int64_t up = ((int64_t)sp * m_pad + cr) * kp;
 #pragma unroll
             for (int k = 0; k < UC; ++k) {
                 const int c = lane + 64 * k;
-                if (c < V) uu[k] += up[c];
+                if (c < V) uu[k] += ut_f<UB>(ut, up + c);
             }
         }
 #pragma unroll
@@ -755,14 +874,14 @@ __global__ __launch_bounds__(256) void xent_finish_kernel(const float* __restric
     }
     for (int c = lane; c < V; c += 64) {
         float u = 0.f;
-        for (int sp = 0; sp < splits; ++sp) u += ut[((int64_t)sp * m_pad + cr) * kp + c];
+        for (int sp = 0; sp < splits; ++sp) u += ut_f<UB>(ut, ((int64_t)sp * m_pad + cr) * kp + c);
         const float dyh = coef * (u * inv_se - ElemTraits<T>::load(w, (int64_t)id * kp + c));
         dot += dyh * (y ? y[(int64_t)m * ldy + c] * rn : ElemTraits<T>::load(yhat, (int64_t)cr * kp + c) * inv_q);
     }
     dot = wave_sum(dot);
     for (int c = lane; c < V; c += 64) {
         float u = 0.f;
-        for (int sp = 0; sp < splits; ++sp) u += ut[((int64_t)sp * m_pad + cr) * kp + c];
+        for (int sp = 0; sp < splits; ++sp) u += ut_f<UB>(ut, ((int64_t)sp * m_pad + cr) * kp + c);
         const float dyh = coef * (u * inv_se - ElemTraits<T>::load(w, (int64_t)id * kp + c));
         const float yh = y ? y[(int64_t)m * ldy + c] * rn : ElemTraits<T>::load(yhat, (int64_t)cr * kp + c) * inv_q;
         store_any(dy.data, dy.dtype, drow + c, normal ? (dyh - yh * dot) * rn : dyh * rn);
@@ -855,7 +974,7 @@ extern "C" int c1v_l2norm_rows(const c1v_l2norm_args* a, void* stream) {
 }
 
 template <int CB, int MODE, int MB>
-static int launch_vs_mb(const bf16_raw* yhat, int M, const bf16_raw* w, int N, int n_base, int splits, float* ut, int m_pad, int ones_col,
+static int launch_vs_mb(const bf16_raw* yhat, int M, const bf16_raw* w, int N, int n_base, int splits, float* ut, int ut_bf16, int m_pad, int ones_col,
                         float* ps, int* pi, const int* ctl, hipStream_t st) {
     using Cfg = VsCfg<CB>;
     static bool once = (hipFuncSetAttribute((const void*)vocab_stream_kernel<CB, MODE, MB>, hipFuncAttributeMaxDynamicSharedMemorySize, VS_STAGES * Cfg::STAGE), true);
@@ -863,35 +982,35 @@ static int launch_vs_mb(const bf16_raw* yhat, int M, const bf16_raw* w, int N, i
     const int tiles_total = (int)c1v_cdiv(N, VS_BN);
     const int tps = (int)c1v_cdiv(tiles_total, splits);
     dim3 grid((unsigned)c1v_cdiv(m_pad, VS_BM * MB), (unsigned)splits);
-    hipLaunchKernelGGL((vocab_stream_kernel<CB, MODE, MB>), grid, dim3(256), VS_STAGES * Cfg::STAGE, st, yhat, M, w, N, n_base, tiles_total, tps, ut, m_pad, ones_col, ps, pi, ctl);
+    hipLaunchKernelGGL((vocab_stream_kernel<CB, MODE, MB>), grid, dim3(256), VS_STAGES * Cfg::STAGE, st, yhat, M, w, N, n_base, tiles_total, tps, ut, ut_bf16, m_pad, ones_col, ps, pi, ctl);
     C1V_LAUNCH_CHECK();
     return 0;
 }
 
 template <int CB, int MODE>
-static int launch_vs(const bf16_raw* yhat, int M, const bf16_raw* w, int N, int n_base, int splits, float* ut, int m_pad, int ones_col,
+static int launch_vs(const bf16_raw* yhat, int M, const bf16_raw* w, int N, int n_base, int splits, float* ut, int ut_bf16, int m_pad, int ones_col,
                      float* ps, int* pi, const int* ctl, hipStream_t st) {
     if constexpr (MODE != VS_ACCUM) {
         // 256-row workgroups when they still fill the chip (and the grid is not a device-dealt pool)
         if (ctl == nullptr && c1v_cdiv(m_pad, 2 * VS_BM) * splits >= 256)
-            return launch_vs_mb<CB, MODE, 2>(yhat, M, w, N, n_base, splits, ut, m_pad, ones_col, ps, pi, ctl, st);
+            return launch_vs_mb<CB, MODE, 2>(yhat, M, w, N, n_base, splits, ut, ut_bf16, m_pad, ones_col, ps, pi, ctl, st);
     }
-    return launch_vs_mb<CB, MODE, 1>(yhat, M, w, N, n_base, splits, ut, m_pad, ones_col, ps, pi, ctl, st);
+    return launch_vs_mb<CB, MODE, 1>(yhat, M, w, N, n_base, splits, ut, ut_bf16, m_pad, ones_col, ps, pi, ctl, st);
 }
 
 // widths (elements per row of Yhat / W) the fused stream kernel is instantiated for
 static inline bool vs_fused_width(int kp) { return kp == 32 || (kp % 64 == 0 && kp >= 64 && kp <= 320); }
 
 template <int MODE>
-static int dispatch_vs(int kp, const bf16_raw* yhat, int M, const bf16_raw* w, int N, int n_base, int splits, float* ut, int m_pad, int ones_col,
+static int dispatch_vs(int kp, const bf16_raw* yhat, int M, const bf16_raw* w, int N, int n_base, int splits, float* ut, int ut_bf16, int m_pad, int ones_col,
                        float* ps, int* pi, const int* ctl, hipStream_t st) {
     switch (kp) {
-        case 32:  return launch_vs<1, MODE>(yhat, M, w, N, n_base, splits, ut, m_pad, ones_col, ps, pi, ctl, st);
-        case 64:  return launch_vs<2, MODE>(yhat, M, w, N, n_base, splits, ut, m_pad, ones_col, ps, pi, ctl, st);
-        case 128: return launch_vs<4, MODE>(yhat, M, w, N, n_base, splits, ut, m_pad, ones_col, ps, pi, ctl, st);
-        case 192: return launch_vs<6, MODE>(yhat, M, w, N, n_base, splits, ut, m_pad, ones_col, ps, pi, ctl, st);
-        case 256: return launch_vs<8, MODE>(yhat, M, w, N, n_base, splits, ut, m_pad, ones_col, ps, pi, ctl, st);
-        case 320: return launch_vs<10, MODE>(yhat, M, w, N, n_base, splits, ut, m_pad, ones_col, ps, pi, ctl, st);
+        case 32:  return launch_vs<1, MODE>(yhat, M, w, N, n_base, splits, ut, ut_bf16, m_pad, ones_col, ps, pi, ctl, st);
+        case 64:  return launch_vs<2, MODE>(yhat, M, w, N, n_base, splits, ut, ut_bf16, m_pad, ones_col, ps, pi, ctl, st);
+        case 128: return launch_vs<4, MODE>(yhat, M, w, N, n_base, splits, ut, ut_bf16, m_pad, ones_col, ps, pi, ctl, st);
+        case 192: return launch_vs<6, MODE>(yhat, M, w, N, n_base, splits, ut, ut_bf16, m_pad, ones_col, ps, pi, ctl, st);
+        case 256: return launch_vs<8, MODE>(yhat, M, w, N, n_base, splits, ut, ut_bf16, m_pad, ones_col, ps, pi, ctl, st);
+        case 320: return launch_vs<10, MODE>(yhat, M, w, N, n_base, splits, ut, ut_bf16, m_pad, ones_col, ps, pi, ctl, st);
         default: return 1;   // no fused instantiation for this width
     }
 }
@@ -933,7 +1052,7 @@ static int xent_accum_unfused(const c1v_xent_accum_args* a, hipStream_t st) {
             t.D = (const char*)a->logits; t.ldd_b = (int64_t)a->m_pad * es; t.J = a->M; t.Ja = a->m_pad;
             t.r_begin = 0; t.r_end = ncount; t.rows_per_split = c1v_cdiv(c1v_cdiv(ncount, spc), 64) * 64;   // whole tiles per split
             t.a_shift0 = 0; t.taps = 1; t.flip = 0; t.tap_stride = 0; t.si = 1; t.sj = a->kp;
-            t.out = a->ut + (int64_t)ch * spc * a->kp * a->m_pad + (a->ones_col / 128 * 128); t.slab_stride = (int64_t)a->kp * a->m_pad; t.splits = spc;
+            t.out = (float*)a->ut + (int64_t)ch * spc * a->kp * a->m_pad + (a->ones_col / 128 * 128); t.slab_stride = (int64_t)a->kp * a->m_pad; t.splits = spc;
             rc = c1v_launch_tn(a->dtype, t, st);
         } else {
             TnParams t{};
@@ -941,7 +1060,7 @@ static int xent_accum_unfused(const c1v_xent_accum_args* a, hipStream_t st) {
             t.D = (const char*)a->logits; t.ldd_b = (int64_t)a->m_pad * es; t.J = a->M; t.Ja = a->m_pad;
             t.r_begin = 0; t.r_end = ncount; t.rows_per_split = c1v_cdiv(c1v_cdiv(ncount, spc), 64) * 64;   // whole tiles per split
             t.a_shift0 = 0; t.taps = 1; t.flip = 0; t.tap_stride = 0; t.si = 1; t.sj = a->kp;
-            t.out = a->ut + (int64_t)ch * spc * a->kp * a->m_pad; t.slab_stride = (int64_t)a->kp * a->m_pad; t.splits = spc;
+            t.out = (float*)a->ut + (int64_t)ch * spc * a->kp * a->m_pad; t.slab_stride = (int64_t)a->kp * a->m_pad; t.splits = spc;
             rc = c1v_launch_tn(a->dtype, t, st);
         }
         if (rc) return rc;
@@ -956,13 +1075,17 @@ extern "C" int c1v_cos_softmax_accum(const c1v_xent_accum_args* a, void* stream)
     C1V_REQUIRE(a->n_pad % VS_BN == 0 && a->n_pad >= a->N, "cos_softmax_accum: n_pad (%d) must be a multiple of %d covering N", a->n_pad, VS_BN);
     C1V_REQUIRE(a->ones_col >= 0 && a->ones_col < a->kp, "cos_softmax_accum: ones_col out of range");
     hipStream_t st = (hipStream_t)stream;
+    const int ub = a->ut_dtype == C1V_BF16;
+    C1V_REQUIRE(a->ut_dtype == C1V_F32 || (ub && a->dtype == C1V_BF16 && a->need_u && vs_fused_width(a->kp)),
+                "cos_softmax_accum: bf16 `ut` slabs are written by the fused bf16 kernel with need_u = 1 only (dtype %d, need_u %d, kp %d)",
+                a->dtype, a->need_u, a->kp);
     if (a->dtype == C1V_BF16) {
         if (a->live_ctl) {
             C1V_REQUIRE(vs_fused_width(a->kp), "cos_softmax_accum: live_ctl needs the fused stream kernel (kp = 32 or a multiple of 64 up to 320; got %d)", a->kp);
         }
         int rc = a->need_u
-            ? dispatch_vs<VS_ACCUM>(a->kp, (const bf16_raw*)a->yhat, a->M, (const bf16_raw*)a->w, a->N, 0, a->splits, a->ut, a->m_pad, a->ones_col, nullptr, nullptr, a->live_ctl, st)
-            : dispatch_vs<VS_SUMEXP>(a->kp, (const bf16_raw*)a->yhat, a->M, (const bf16_raw*)a->w, a->N, 0, a->splits, a->ut, a->m_pad, a->ones_col, nullptr, nullptr, a->live_ctl, st);
+            ? dispatch_vs<VS_ACCUM>(a->kp, (const bf16_raw*)a->yhat, a->M, (const bf16_raw*)a->w, a->N, 0, a->splits, (float*)a->ut, ub, a->m_pad, a->ones_col, nullptr, nullptr, a->live_ctl, st)
+            : dispatch_vs<VS_SUMEXP>(a->kp, (const bf16_raw*)a->yhat, a->M, (const bf16_raw*)a->w, a->N, 0, a->splits, (float*)a->ut, 0, a->m_pad, a->ones_col, nullptr, nullptr, a->live_ctl, st);
         if (rc <= 0) return rc;
     }
     C1V_REQUIRE(a->live_ctl == nullptr, "cos_softmax_accum: live_ctl is only supported by the fused bf16 stream kernel");
@@ -994,12 +1117,14 @@ extern "C" int c1v_cos_softmax_finish(const c1v_xent_finish_args* a, void* strea
     const int M = a->B * a->T;
     static const size_t lds = getenv("C1V_FINISH_LDS") ? (size_t)atoi(getenv("C1V_FINISH_LDS")) : 0;   // diagnostic: caps the resident waves per CU
     dim3 grid((unsigned)c1v_cdiv(M, 4));
-    if (a->dtype == C1V_F32)
-        hipLaunchKernelGGL(xent_finish_kernel<float>, grid, dim3(256), lds, (hipStream_t)stream, a->ut, a->splits, a->kp, a->m_pad, a->ones_col,
-                           (const float*)a->yhat, (const float*)a->w, a->rnorm, a->qscale, a->ids, a->B, a->T, a->V, a->B_global, a->xent_rows, a->dy, a->y, a->ldy, a->pos, a->live_ctl);
-    else
-        hipLaunchKernelGGL(xent_finish_kernel<bf16_raw>, grid, dim3(256), lds, (hipStream_t)stream, a->ut, a->splits, a->kp, a->m_pad, a->ones_col,
-                           (const bf16_raw*)a->yhat, (const bf16_raw*)a->w, a->rnorm, a->qscale, a->ids, a->B, a->T, a->V, a->B_global, a->xent_rows, a->dy, a->y, a->ldy, a->pos, a->live_ctl);
+    C1V_REQUIRE(a->ut_dtype == C1V_F32 || (a->ut_dtype == C1V_BF16 && a->dtype == C1V_BF16), "cos_softmax_finish: bf16 `ut` slabs come from the bf16 kernel only");
+#define C1V_FINISH(ELEM, UB) hipLaunchKernelGGL((xent_finish_kernel<ELEM, UB>), grid, dim3(256), lds, (hipStream_t)stream, (const float*)a->ut, a->splits, a->kp, \
+        a->m_pad, a->ones_col, (const ELEM*)a->yhat, (const ELEM*)a->w, a->rnorm, a->qscale, a->ids, a->B, a->T, a->V, a->B_global, a->xent_rows, a->dy, a->y, \
+        a->ldy, a->pos, a->live_ctl)
+    if (a->dtype == C1V_F32) C1V_FINISH(float, false);
+    else if (a->ut_dtype == C1V_BF16) C1V_FINISH(bf16_raw, true);
+    else C1V_FINISH(bf16_raw, false);
+#undef C1V_FINISH
     C1V_LAUNCH_CHECK();
     return 0;
 }
@@ -1025,7 +1150,7 @@ extern "C" int c1v_vocab_argmax(const c1v_vocab_argmax_args* a, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (a->dtype == C1V_BF16 && a->part_score && a->part_idx && a->splits > 0 && a->m_pad % VS_BM == 0 && a->m_pad >= a->M &&
         a->n_pad % VS_BN == 0 && a->n_pad >= a->N) {
-        int rc = dispatch_vs<VS_ARGMAX>(a->kp, (const bf16_raw*)a->q, a->M, (const bf16_raw*)a->w, a->N, a->n_base, a->splits, nullptr, a->m_pad, 0,
+        int rc = dispatch_vs<VS_ARGMAX>(a->kp, (const bf16_raw*)a->q, a->M, (const bf16_raw*)a->w, a->N, a->n_base, a->splits, nullptr, 0, a->m_pad, 0,
                                         a->part_score, a->part_idx, nullptr, st);
         if (rc < 0) return rc;
         if (rc == 0) {
@@ -1136,7 +1261,7 @@ extern "C" int c1v_vocab_argmax_noalloc(const c1v_vocab_argmax_noalloc_args* a, 
     hipStream_t st = (hipStream_t)stream;
     // every (split, row < m_pad) cell of the partial results is written by the stream kernel before the merge reads it, so
     // nothing of the previous call's contents has to be cleared
-    int rc = dispatch_vs<VS_ARGMAX>(a->kp, (const bf16_raw*)a->q, a->M, (const bf16_raw*)a->w, a->N, a->n_base, (int)splits, nullptr, (int)m_pad, 0,
+    int rc = dispatch_vs<VS_ARGMAX>(a->kp, (const bf16_raw*)a->q, a->M, (const bf16_raw*)a->w, a->N, a->n_base, (int)splits, nullptr, 0, (int)m_pad, 0,
                                     part_score, part_idx, nullptr, st);
     if (rc != 0) { if (rc > 0) c1v_set_error("vocab_argmax_noalloc: no fused kernel for kp = %d", a->kp); return rc < 0 ? rc : -1; }
     hipLaunchKernelGGL(argmax_merge_kernel, dim3((unsigned)c1v_cdiv(a->M, 256)), dim3(256), 0, st, part_score, part_idx, (int)splits, m_pad, a->M,

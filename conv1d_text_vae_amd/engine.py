@@ -198,7 +198,10 @@ class VAEEngine:
         pitch = _even(To + 2 * (k - 1))
         self.Xf = seqbuf(B, pitch, geom.pad_left, To, c_in)
         self.dOf = seqbuf(B, pitch, k - 1, To, self.V)
-        self.Y = Buf(z(B * To * self.V + 64), B, To * self.V, 0, To, self.V, self.V)
+        # (rows padded to whole 16-byte words: the final convolution's epilogue then stores float4 instead of float2 -- its
+        # fp32 output is the largest write of the step -- and the readers take the pitch `Vp`)
+        self.Vp = _pad(self.V, 4)
+        self.Y = Buf(z(B * To * self.Vp + 64), B, To * self.Vp, 0, To, self.Vp, self.V)
         # use_batch_norm: the normalisation needs the convolutions' own (post-ReLU, un-pooled / un-upsampled) outputs and the
         # gradients w.r.t. the pooled / upsampled tensors as buffers of their own
         self.Ae: List[Buf] = []
@@ -319,6 +322,9 @@ class VAEEngine:
         self.row_pos = torch.full((self.m_pad,), -1, dtype=torch.int32, device=self.dev)
         self.live_ctl = torch.zeros(4, dtype=torch.int32, device=self.dev)
         self.ut = torch.zeros(self.max_splits * self.kp * self.m_pad, dtype=torch.float32, device=self.dev)
+        # the training pass of the fused kernel writes its partial sums as bf16 (half the bytes out of the kernel and
+        # into c1v_cos_softmax_finish, which sums them in fp32); C1V_UT_F32=1 keeps fp32 slabs (A/B measurements)
+        self.ut_code = L.BF16 if fused and os.environ.get('C1V_UT_F32', '0') != '1' else L.F32
         if hasattr(self, '_ops_built'):
             self._build_ops()
 
@@ -577,11 +583,11 @@ class VAEEngine:
         self.ops_dec_infer = dec_fwd(False) if bn else self.ops_dec_train
         self.ops_dec = self.ops_dec_train
         self.ops_post = []
-        f_eos = self.lib.c1v_eos_truncate_normalize
+        f_eos = self.lib.c1v_eos_truncate_normalize_ld
 
         def run_post():
-            L.check(f_eos(self.Y.t.data_ptr(), B, g.output_text_size, self.V, self.post.data_ptr(),
-                          self.end_idx.data_ptr(), self._stream()), 'c1v_eos_truncate_normalize')
+            L.check(f_eos(self.Y.t.data_ptr(), self.Vp, B, g.output_text_size, self.V, self.post.data_ptr(),
+                          self.end_idx.data_ptr(), self._stream()), 'c1v_eos_truncate_normalize_ld')
         self.ops_post = [run_post]
         self._ops_built = True
         if self.N == 0:
@@ -600,17 +606,19 @@ class VAEEngine:
                                          self.max_splits, self.row_pos.data_ptr(), self.live_ctl.data_ptr())
 
         def loss_ops(train: bool):
-            ops = [op('c1v_l2norm_rows', L.L2NormArgs(self.Y.t.data_ptr(), self.M, self.V, self.V, self.yhat.data_ptr(),
+            ops = [op('c1v_l2norm_rows', L.L2NormArgs(self.Y.t.data_ptr(), self.M, self.V, self.Vp, self.yhat.data_ptr(),
                                                       self.code, self.kp, self.rnorm.data_ptr(), self.qscale, pos_ptr))]
             ops.append(op('c1v_cos_softmax_accum', L.XentAccumArgs(
                 self.yhat.data_ptr(), self.code, self.M, self.kp, self.w_vocab.data_ptr(), self.N, self.n_pad,
                 self.ut.data_ptr(), self.m_pad, self.x_splits, 1 if train else 0, self.ones_col,
-                self.logits.data_ptr() if self.logits is not None else None, self.n_chunk, ctl_ptr)))
+                self.logits.data_ptr() if self.logits is not None else None, self.n_chunk, ctl_ptr,
+                self.ut_code if train else L.F32)))
             ops.append(op('c1v_cos_softmax_finish', L.XentFinishArgs(
                 self.ut.data_ptr(), self.x_splits, self.kp, self.m_pad, self.ones_col, self.yhat.data_ptr(),
                 self.w_vocab.data_ptr(), self.code, self.rnorm.data_ptr(), self.qscale, self.ids_in.data_ptr(), B,
                 g.output_text_size, self.V, self.Bg, self.xent_rows.data_ptr(), self.xent_b.data_ptr(),
-                self.dOf.seq() if train else _null_seq(), self.Y.t.data_ptr(), self.V, pos_ptr, ctl_ptr)))
+                self.dOf.seq() if train else _null_seq(), self.Y.t.data_ptr(), self.Vp, pos_ptr, ctl_ptr,
+                self.ut_code if train else L.F32)))
             core = list(ops)
             ops = self.ops_live_rows + ops
             f_red = self.lib.c1v_loss_reduce
@@ -1156,8 +1164,7 @@ class VAEEngine:
             self._graph('recon_post' if postprocess else 'recon', ops)
         else:
             self._run(ops)
-        return self.post if postprocess else self.Y.t[: self.B * self.g.output_text_size * self.V].view(
-            self.B, self.g.output_text_size, self.V)
+        return self.post if postprocess else self._y_view()
 
     def decode_latent(self, z: torch.Tensor) -> torch.Tensor:
         """vae_decoder_.predict_on_batch(z): z [B, latent] fp32 -> y [B, T_out, V] fp32."""
@@ -1165,10 +1172,15 @@ class VAEEngine:
         self.mlv_parts.zero_()
         self.mlv[:, :self.D].copy_(z)
         self._run(self.ops_lat_infer + self.ops_dec_infer)
-        return self.Y.t[: self.B * self.g.output_text_size * self.V].view(self.B, self.g.output_text_size, self.V)
+        return self._y_view()
 
     def y_pred(self) -> torch.Tensor:
-        return self.Y.t[: self.B * self.g.output_text_size * self.V].view(self.B, self.g.output_text_size, self.V)
+        return self._y_view()
+
+    def _y_view(self) -> torch.Tensor:
+        """The decoder output [B, T_out, V] fp32 (a strided view: rows lie `Vp` values apart)."""
+        To = self.g.output_text_size
+        return self.Y.t[: self.B * To * self.Vp].view(self.B, To, self.Vp)[:, :, :self.V]
 
 
 class VocabDecoder:

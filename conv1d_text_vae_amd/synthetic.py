@@ -18,18 +18,23 @@ def synthetic_vocab(n_words: int, emb: int, seed: int = 1234) -> np.ndarray:
     return W
 
 
-def synthetic_batch(W_in: np.ndarray, n_out_rows: int, batch: int, t_in: int, t_out: int, seed: int = 1234):
+def synthetic_batch(W_in: np.ndarray, n_out_rows: int, batch: int, t_in: int, t_out: int, seed: int = 1234,
+                    with_input_ids: bool = False):
     """x [B, T_in, V] float32 and target ids [B, T_out] int32 (-1 = no target): word rows for t < len, the EOS row at
-    t == len, zeros after; lengths ~ U{3..T-1}."""
+    t == len, zeros after; lengths ~ U{3..T-1}.  with_input_ids: also the rows of W_in that make up x, [B, T_in] int32
+    (-1 = all-zero row) -- the form fit() feeds the engine (c1v_gather_input)."""
     rng = np.random.Generator(np.random.PCG64(seed + 1))
     n_in = W_in.shape[0]
-    x = np.zeros((batch, t_in, W_in.shape[1]), dtype=np.float32)
+    in_ids = np.full((batch, t_in), -1, dtype=np.int32)
     ids = np.full((batch, t_out), -1, dtype=np.int32)
     li = rng.integers(3, t_in, size=batch)
     lo = rng.integers(3, t_out, size=batch)
     for b in range(batch):
-        x[b, :li[b]] = W_in[rng.integers(0, n_in - 2, size=li[b])]
-        x[b, li[b]] = W_in[n_in - 1]
+        in_ids[b, :li[b]] = rng.integers(0, n_in - 2, size=li[b])
+        in_ids[b, li[b]] = n_in - 1
         ids[b, :lo[b]] = rng.integers(0, n_out_rows - 2, size=lo[b])
         ids[b, lo[b]] = n_out_rows - 1
-    return x, ids
+    x = np.zeros((batch, t_in, W_in.shape[1]), dtype=np.float32)
+    keep = in_ids >= 0
+    x[keep] = W_in[in_ids[keep]]
+    return (x, ids, in_ids) if with_input_ids else (x, ids)

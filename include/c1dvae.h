@@ -279,7 +279,7 @@ typedef struct c1v_xent_accum_args {
     const void* yhat; int32_t dtype; int32_t M, kp;
     const void* w;    /* [n_pad][kp] T, rows >= N zero, column ones_col = 1.0 on rows < N */
     int32_t N, n_pad;
-    float* ut;        /* [splits][m_pad][kp] f32 */
+    void* ut;         /* [splits][m_pad][kp] f32 -- or bf16 when ut_dtype == C1V_BF16 (below) */
     int32_t m_pad, splits;
     int32_t need_u;   /* 0: only the sum-exp row `ones_col` is produced (validation loss) */
     int32_t ones_col;
@@ -288,11 +288,13 @@ typedef struct c1v_xent_accum_args {
     const int32_t* live_ctl;   /* optional DEVICE int[4] from c1v_live_rows (fused bf16 kernel only): yhat holds ctl[0] compacted
                                   rows; the grid of (m_pad/128) x splits workgroups is re-dealt on the device to ctl[1] row tiles
                                   x ctl[2] vocabulary splits, so ut must hold max_splits slabs (see c1v_live_rows) */
+    int32_t ut_dtype;          /* C1V_F32 (default) or C1V_BF16: element type of the `ut` slabs.  bf16 slabs halve the bytes the
+                                  finish step reads (splits x n_live x kp); only the fused bf16 kernel with need_u = 1 writes them */
 } c1v_xent_accum_args;
 int c1v_cos_softmax_accum(const c1v_xent_accum_args*, void* stream);
 
 typedef struct c1v_xent_finish_args {
-    const float* ut; int32_t splits, kp, m_pad, ones_col;
+    const void* ut; int32_t splits, kp, m_pad, ones_col;
     const void* yhat; const void* w; int32_t dtype;
     const float* rnorm; float qscale;
     const int32_t* ids;       /* [B*T] target id or -1 */
@@ -304,6 +306,7 @@ typedef struct c1v_xent_finish_args {
     const float* y; int64_t ldy;   /* optional fp32 decoder output [M][ldy]: yhat = y*rnorm in fp32 for the normalisation backward */
     const int32_t* pos;            /* optional: compact row of yhat / ut for sample row m (c1v_live_rows); < 0: no target */
     const int32_t* live_ctl;       /* optional: number of ut slabs = live_ctl[2] instead of `splits` */
+    int32_t ut_dtype;              /* element type of the `ut` slabs, as given to c1v_cos_softmax_accum */
 } c1v_xent_finish_args;
 int c1v_cos_softmax_finish(const c1v_xent_finish_args*, void* stream);
 /* Rows without a target (ids[m] < 0: padding behind the end of a text) contribute exactly zero to the loss and to its
@@ -360,6 +363,8 @@ int c1v_nadam_advance(double* state, float* sched, const float* sq_partial, int3
 /* ---- a10-i: EOS truncation + renormalisation (:542-565) ------------------------------------------------------
  * y [B][T][V] f32 -> out [B][T][V-1] f32, end_idx[B] */
 int c1v_eos_truncate_normalize(const float* y, int32_t B, int32_t T, int32_t V, float* out, int32_t* end_idx, void* stream);
+/* the same on rows that lie `ldy` >= V values apart (the engine pads the decoder output's rows to whole 16-byte words) */
+int c1v_eos_truncate_normalize_ld(const float* y, int64_t ldy, int32_t B, int32_t T, int32_t V, float* out, int32_t* end_idx, void* stream);
 /* float64 variant: the reference's static helper keeps the dtype of its NumPy argument (:547-550) and its known-answer
  * tests compare float64 values to 7 places (tests/test_conv1d_text_vae.py:1544-1605) */
 int c1v_eos_truncate_normalize_f64(const double* y, int32_t B, int32_t T, int32_t V, double* out, int32_t* end_idx, void* stream);
