@@ -66,6 +66,7 @@ __device__ __forceinline__ void gather_input_body(const float* __restrict__ tabl
                                                   int T_len, int C, const c1v_seq& dst, int blk, int nblk) {
     const int g8 = dst.cp >> 3;
     const int64_t total = (int64_t)dst.batch * T_len * g8;
+    const bool vec = (ld & 3) == 0 && (((uintptr_t)table) & 15) == 0;
     for (int64_t i = blk * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)nblk * blockDim.x) {
         int c0, t;
         int64_t row, b;
@@ -77,10 +78,18 @@ __device__ __forceinline__ void gather_input_body(const float* __restrict__ tabl
         }
         const int id = ids[row];
         float v[8];
+        if (vec && c0 + 8 <= ld) {                 // two 16-byte words of the table row (rows padded to whole words)
+            const float4* p = (const float4*)(table + (int64_t)(id >= 0 ? id : 0) * ld + c0);
+            const float4 a = p[0], b4 = p[1];
+            const float t8[8] = {a.x, a.y, a.z, a.w, b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const float t2 = table[(int64_t)(id >= 0 ? id : 0) * ld + (c0 + k < C ? c0 + k : C - 1)];
-            v[k] = (c0 + k < C && id >= 0) ? t2 : 0.0f;
+            for (int k = 0; k < 8; ++k) v[k] = (c0 + k < C && id >= 0) ? t8[k] : 0.0f;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float t2 = table[(int64_t)(id >= 0 ? id : 0) * ld + (c0 + k < C ? c0 + k : C - 1)];
+                v[k] = (c0 + k < C && id >= 0) ? t2 : 0.0f;
+            }
         }
         store8<T>(dst, b * dst.bstride + (int64_t)(dst.off + t) * dst.cp + c0, v);
     }

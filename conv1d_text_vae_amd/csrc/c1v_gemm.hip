@@ -120,7 +120,11 @@ int c1v_fill_epi(const c1v_epilogue& e, EpiDev& d, int M, int Le, int nrows, int
     const bool masks = e.sel != nullptr || e.keep != nullptr;
     for (int vw = 4; vw >= 2 && d.fastw == 0; vw -= 2) {
         auto al = [&](const void* p, int esize) { return ((uintptr_t)p % (uintptr_t)(vw * esize)) == 0; };
-        bool ok = N % vw == 0 && (e.reshape_w <= 0 || e.reshape_w % 4 == 0);
+        // (a plain fp32/bf16 STORE whose rows are padded to whole 4-channel groups may end in a partial group: the group's
+        // surplus values land in the row's padding)
+        const bool pad_tail = vw == 4 && e.row_mode == C1V_ROW_STORE && e.reshape_w <= 0 && e.act.data == nullptr && !masks &&
+                              e.dst.cp >= (N + 3) / 4 * 4;
+        bool ok = (N % vw == 0 || pad_tail) && (e.reshape_w <= 0 || e.reshape_w % 4 == 0);
         ok = ok && al(e.dst.data, c1v_esize(e.dst.dtype)) && e.dst.bstride % vw == 0 && e.dst.cp % vw == 0;
         ok = ok && (e.bias == nullptr || al(e.bias, 4));
         if (e.act.data) ok = ok && al(e.act.data, c1v_esize(e.act.dtype)) && e.act.bstride % vw == 0 && e.act.cp % vw == 0;

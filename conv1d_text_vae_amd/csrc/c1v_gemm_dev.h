@@ -232,7 +232,7 @@ struct EpiState {
     uint4 x1[CH], x2[CH];  // LATENT_BWD only: z_log_var and eps of the group
     uint32_t by[CH];       // four mask bytes
     uint32_t flags;        // 4 bits per row: 1 = stored, 2 = UP2: second row fits / PAIRSUM: first member valid, 4 = PAIRSUM: second member valid
-    int cnt;               // valid channels of the group (VW = 4: always 4; VW = 2: 2 or 4); 0 = thread idle
+    int cnt;               // valid channels of the group (VW = 4: 4, or 1..3 in a padded row's last group; VW = 2: 2 or 4); 0 = thread idle
 };
 
 template <int VW> __device__ __forceinline__ uint4 epi_ld_act(const EpiDev& e, int64_t i, int cnt) {
@@ -287,7 +287,8 @@ __device__ __forceinline__ void epi_load(const EpiDev& e, const RowDiv& rd, EpiS
     const int n = n0 + 4 * g;
     st.flags = 0; st.cnt = 0;
     if (n >= e.N) return;
-    const int cnt = (VW == 4 || e.N - n >= 4) ? 4 : 2;
+    // (VW = 4 with a partial last group -- c1v_fill_epi's pad_tail: the words are whole, cnt tells STORE which values to zero)
+    const int cnt = VW == 4 ? (e.N - n >= 4 ? 4 : e.N - n) : (e.N - n >= 4 ? 4 : 2);
     st.cnt = cnt;
     int tn = 0, c = n;
     if (e.reshape_w > 0) { tn = n / e.reshape_w; c = n - tn * e.reshape_w; }
@@ -387,6 +388,7 @@ __device__ __forceinline__ void epi_finish(const EpiDev& e, const EpiState& st, 
             for (int k = 0; k < 4; ++k) {
                 v[k] *= am[k];
                 if (e.keep) v[k] = ((by >> (8 * k)) & 255u) ? v[k] * e.keep_scale : 0.0f;
+                if (VW == 4 && k >= cnt) v[k] = 0.0f;           // row padding behind channel N stays zero
             }
             epi_st<VW>(e, d, v, cnt);
         } else if (MODE == C1V_ROW_UP2) {
@@ -603,7 +605,11 @@ __device__ __forceinline__ void nt_body(const NtParams& p, const int bx, const i
             }
         } else if (ev.bias) {
             if (fastw == 4) {
-                if (nbias < ev.N) { const float4 b = *(const float4*)(ev.bias + nbias); bias4[0] = b.x; bias4[1] = b.y; bias4[2] = b.z; bias4[3] = b.w; }
+                if (nbias + 3 < ev.N) { const float4 b = *(const float4*)(ev.bias + nbias); bias4[0] = b.x; bias4[1] = b.y; bias4[2] = b.z; bias4[3] = b.w; }
+                else {                                       // partial last group (rows padded beyond N): stay inside the bias vector
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) bias4[k] = nbias + k < ev.N ? ev.bias[nbias + k] : 0.0f;
+                }
             } else if (fastw == 2) {
                 if (nbias < ev.N) { const float2 b = *(const float2*)(ev.bias + nbias); bias4[0] = b.x; bias4[1] = b.y; }
                 if (nbias + 2 < ev.N) { const float2 b = *(const float2*)(ev.bias + nbias + 2); bias4[2] = b.x; bias4[3] = b.y; }

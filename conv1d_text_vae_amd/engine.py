@@ -959,7 +959,10 @@ class VAEEngine:
         t = np.ascontiguousarray(table, dtype=np.float32)
         if t.ndim != 2 or t.shape[1] != self.g.input_vector_size:
             raise ValueError('input table must be [N, {0}]'.format(self.g.input_vector_size))
-        self.in_table = torch.from_numpy(t).to(self.dev)
+        # (rows padded to whole 16-byte words: c1v_gather_input then reads a row as float4 words)
+        ld = _pad(t.shape[1], 4)
+        self.in_table = torch.zeros(t.shape[0], ld, dtype=torch.float32, device=self.dev)
+        self.in_table[:, :t.shape[1]].copy_(torch.from_numpy(t))
         self.in_ids = torch.full((self.B, self.g.input_text_size), -1, dtype=torch.int32, device=self.dev)
         self._build_gather()
         self._graphs = {k: v for k, v in self._graphs.items() if not k.endswith('@ids')}
