@@ -561,6 +561,14 @@ __device__ __forceinline__ void nt_body(const NtParams& p, const int bx, const i
         const int64_t tap_b = (int64_t)p.k_strips * 128;
         auto issue = [&](int kt) {
             char* d = smem + (kt % NS) * STAGE + dst0;
+#if defined(NT_ABLATE) && (NT_ABLATE & 1)
+            // diagnostic (wrong results): the A feeder only fetches tap 0 of every strip -- an upper bound for what an
+            // activation-window kernel (one A fetch for all taps) could gain
+            if (!(wave == 4 && p.k_taps > 1 && tap_i != 0))
+#endif
+#if defined(NT_ABLATE) && (NT_ABLATE & 2)
+            if (kt < 0)                                    // diagnostic: no operand requests at all (compute side alone)
+#endif
 #pragma unroll
             for (int i = 0; i < IPT; ++i) glds16(src[i] + ko, d + i * 1024);
             if (p.k_taps > 1) {
@@ -632,6 +640,9 @@ __device__ __forceinline__ void nt_body(const NtParams& p, const int bx, const i
         const char* sb = sa + BM * 128;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
+#if defined(NT_ABLATE) && (NT_ABLATE & 4)
+            if (kt >= 0) continue;                         // diagnostic: no fragment reads, no MFMAs (feed side alone)
+#endif
             uint4 af[MI], bf[NJ];
             const int ch = kk * 4 + (lane >> 4);
 #pragma unroll
