@@ -654,12 +654,27 @@ class VAEEngine:
 
         wgrad_rows = int(os.environ.get('C1V_WGRAD_ROWS', '384'))      # sample rows per wgrad split (measured at C2: 384 < 512 < 768)
 
-        def row_splits(rows: int) -> int:
-            return int(max(1, min(32, rows // wgrad_rows)))
+        # Splits of the row (reduction) dimension of a conv wgrad.  Every split is one workgroup per (128 x 128 tile, tap) and
+        # one slab for c1v_grad_finalize to sum.  Small batches: as many as keep `wgrad_rows` rows per split.  Large batches
+        # (C4: 270 k rows; round 1 capped every layer at 32 splits) -- measured per layer at C4, `C1V_WGRAD_WGS` scans in
+        # profiles/r02b_c4_wgrad_splits.txt: what matters is how the wgrad workgroups fill the 2 x 256 workgroup slots of
+        # the chip.  In a paired launch they are dispatched first and each runs for the whole launch next to a stream of
+        # short dgrad tiles: about 192 of them (under one per CU) is best, more only lengthens the longest CU's queue (a
+        # 512-channel layer went from 32 splits = 1536 workgroups to 4 splits: 124 -> 72 us).  A wgrad launched alone (the
+        # first convolution) wants both slots of every CU: just under 512 (one workgroup over a full round doubles the time).
+        wgrad_wgs = int(os.environ.get('C1V_WGRAD_WGS', '192'))
+        wgrad_wgs_alone = int(os.environ.get('C1V_WGRAD_WGS_ALONE', '512'))
+        wgrad_max = int(os.environ.get('C1V_WGRAD_MAX_SPLITS', '128'))
 
-        def conv_wgrad(X: Buf, dO: Buf, wname: str, bname: str, C_in: int, F: int, flip: int, tap_stride, si, sj, frozen=False):
+        def row_splits(rows: int, tile_taps: int, alone: bool) -> int:
+            by_rows = rows // wgrad_rows
+            by_fill = (wgrad_wgs_alone if alone else wgrad_wgs) // max(1, tile_taps)      # (rounded down)
+            return int(max(1, min(by_rows, by_fill, wgrad_max)))
+
+        def conv_wgrad(X: Buf, dO: Buf, wname: str, bname: str, C_in: int, F: int, flip: int, tap_stride, si, sj, frozen=False,
+                       alone=False):
             rows = B * X.pitch
-            sp = row_splits(rows)
+            sp = row_splits(rows, k * (-(-C_in // 128)) * (-(-F // 128)), alone)
             wt = slab(wname, sp, frozen)
             bt = slab(bname, sp, frozen)
             count = int(np.prod(self.seg_shapes[wname]))
@@ -772,7 +787,8 @@ class VAEEngine:
             C_in = g.input_vector_size if l == 0 else g.n_filters[l - 1]
             F = g.n_filters[l]
             nm = 'encoder_conv1d_%d' % (l + 1)
-            wg = conv_wgrad(self.Xe[l], self.dOe[l], nm + '/kernel', nm + '/bias', C_in, F, 0, C_in * F, F, 1, self.frozen)
+            wg = conv_wgrad(self.Xe[l], self.dOe[l], nm + '/kernel', nm + '/bias', C_in, F, 0, C_in * F, F, 1, self.frozen,
+                            alone=(l == 0))                 # the first convolution has no data gradient: its wgrad is a launch of its own
             pre = []
             if bn:
                 bname = 'encoder_batchnorm_%d' % (l + 1)
