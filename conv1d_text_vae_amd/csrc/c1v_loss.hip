@@ -141,11 +141,17 @@ void vocab_stream_kernel(const bf16_raw* __restrict__ yhat, int M, const bf16_ra
         // (A split-major deal that keeps the workgroups of one XCD on one or two vocabulary splits -- so that each L2 fetches
         // 2/splits of W instead of all of it -- was measured at C2: 1 % SLOWER, 49.0 against 48.5 us; W is L2/MALL-resident
         // either way and 32 CUs asking for the same lines at the same time is worse than 5 of them.)
-        const int live = ctl[0], splits = ctl[2];
+        const int live = ctl[0], splits = ctl[2], full = ctl[4];
         const int item = blockIdx.x + gridDim.x * blockIdx.y;
-        bx = item / splits; split = item - bx * splits;
+        if (item < full) {                          // a whole round's row tile: the whole vocabulary, slab 0
+            bx = item; split = 0; tiles_per_split = tiles_total;
+        } else {                                    // the remainder, cut into ctl[2] splits each
+            const int r = item - full;
+            bx = r / splits; split = r - bx * splits; bx += full;
+            tiles_per_split = ctl[3];
+        }
         if (bx * WG_ROWS >= live) return;           // whole workgroup, before any barrier
-        M = live; tiles_per_split = ctl[3];
+        M = live;
     }
     const int m_row0 = bx * WG_ROWS + wave * 32 * MB + l31;      // this lane's row of m-block 0 (m-block mb: + 32 mb)
     const int t_begin = split * tiles_per_split;
@@ -623,7 +629,7 @@ __global__ __launch_bounds__(256) void xent_finish_kernel(const float* __restric
     // live-row compaction: `cr` is the row of yhat / ut that belongs to sample row m; rows without a target have none
     // (wave-uniform values are moved to scalar registers so that the loops over the slabs stay scalar loops)
     const int cr = pos ? __builtin_amdgcn_readfirstlane(pos[m]) : m;
-    if (ctl) splits = __builtin_amdgcn_readfirstlane(ctl[2]);
+    if (ctl) splits = __builtin_amdgcn_readfirstlane((cr >> 7) < ctl[4] ? 1 : ctl[2]);    // (the full row tiles have ONE slab)
     if (cr < 0) {                                   // wave-uniform: no loss term, zero gradient
         if (lane == 0) xent_rows[m] = 0.0f;
         if (dy.data != nullptr) {

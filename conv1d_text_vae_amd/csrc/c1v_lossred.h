@@ -65,12 +65,17 @@ __device__ __forceinline__ void loss_reduce_body(const float* __restrict__ xent_
 
 
 constexpr int VS_BM_ROWS = 128;   // sample rows per workgroup of the vocabulary stream kernel
+constexpr int VS_CUS = 256;       // compute units of an MI355X: workgroups of the stream kernel that run at the same time
 
 // positions of the rows that have a target (ids[m] >= 0) in compact order, -1 for the others, and the work split of the
 // vocabulary stream over them:
-//   ctl[0] = n_live, ctl[1] = live row tiles (128 rows), ctl[2] = vocabulary splits per row tile, ctl[3] = tiles per split
-// The stream kernels are launched with a fixed grid of `items` workgroups (a captured graph cannot resize it); with fewer
-// live row tiles each one is cut into more vocabulary splits so that the grid still covers the chip.
+//   ctl[0] = n_live, ctl[1] = live row tiles (128 rows), ctl[2] = vocabulary splits per TAIL row tile, ctl[3] = tiles per split,
+//   ctl[4] = FULL row tiles: the first ctl[4] row tiles (a multiple of VS_CUS) take the whole vocabulary in one workgroup each
+// The stream kernels are launched with a fixed grid of `items` workgroups (a captured graph cannot resize it) and run one
+// workgroup per CU.  Whole rounds of VS_CUS row tiles need no splitting; the remainder of the row tiles -- all of them, when
+// there are fewer than VS_CUS -- is cut into as many vocabulary splits as make up one more round, so that the last round
+// is as short as its share of the work (1051 row tiles: 4 rounds + 27 tiles x 9 splits, instead of a fifth whole round
+// for 27 workgroups).
 // One workgroup of any whole number of waves <= 16 (also run as a block of c1v_step_prologue): every thread owns a run of
 // consecutive rows (a multiple of 4, read and written as 16-byte words), the runs are scanned through LDS.
 __device__ __forceinline__ void live_rows_body(const int* __restrict__ ids, int M, int items, int vocab_tiles, int max_splits,
@@ -113,10 +118,14 @@ __device__ __forceinline__ void live_rows_body(const int* __restrict__ ids, int 
     if (tid == nthr - 1) {
         const int live = base + incl;
         const int tiles = (live + VS_BM_ROWS - 1) / VS_BM_ROWS;
-        int splits = tiles > 0 ? items / tiles : 1;
+        int full = (tiles / VS_CUS) * VS_CUS;
+        if (full > items) full = (items / VS_CUS) * VS_CUS;   // (cannot happen with a grid that covers all row tiles)
+        const int tail = tiles - full;
+        int splits = tail > 0 ? (full > 0 ? VS_CUS : items) / tail : 1;
+        if (tail > 0 && splits > (items - full) / tail) splits = (items - full) / tail;
         if (splits > max_splits) splits = max_splits;
         if (splits > vocab_tiles) splits = vocab_tiles;
         if (splits < 1) splits = 1;
-        ctl[0] = live; ctl[1] = tiles; ctl[2] = splits; ctl[3] = (vocab_tiles + splits - 1) / splits;
+        ctl[0] = live; ctl[1] = tiles; ctl[2] = splits; ctl[3] = (vocab_tiles + splits - 1) / splits; ctl[4] = full;
     }
 }

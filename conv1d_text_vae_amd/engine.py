@@ -318,9 +318,15 @@ class VAEEngine:
         # on the device into more vocabulary splits per row tile (c1v_live_rows), up to max_splits slabs of `ut`.
         self.compact = fused and os.environ.get('C1V_LIVE_ROWS', '1') == '1'
         tiles_m = max(1, self.m_pad // 128)
-        self.max_splits = max(self.x_splits, min(tiles, 16, (4 * 256) // tiles_m)) if self.compact else self.x_splits
+        if self.compact and tiles_m > 256:
+            # more row tiles than CUs: whole rounds of 256 row tiles run unsplit and only the remainder is cut into
+            # vocabulary splits (c1v_live_rows); the pool of workgroups must hold the row tiles plus one more round
+            self.x_splits = max(self.x_splits, 2)
+            self.max_splits = max(self.x_splits, min(tiles, 8))
+        else:
+            self.max_splits = max(self.x_splits, min(tiles, 16, (4 * 256) // tiles_m)) if self.compact else self.x_splits
         self.row_pos = torch.full((self.m_pad,), -1, dtype=torch.int32, device=self.dev)
-        self.live_ctl = torch.zeros(4, dtype=torch.int32, device=self.dev)
+        self.live_ctl = torch.zeros(8, dtype=torch.int32, device=self.dev)
         self.ut = torch.zeros(self.max_splits * self.kp * self.m_pad, dtype=torch.float32, device=self.dev)
         # the training pass of the fused kernel writes its partial sums as bf16 (half the bytes out of the kernel and
         # into c1v_cos_softmax_finish, which sums them in fp32); C1V_UT_F32=1 keeps fp32 slabs (A/B measurements)

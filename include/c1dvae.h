@@ -285,7 +285,7 @@ typedef struct c1v_xent_accum_args {
     int32_t ones_col;
     float* logits;    /* f32 path scratch [n_chunk][m_pad] */
     int32_t n_chunk;
-    const int32_t* live_ctl;   /* optional DEVICE int[4] from c1v_live_rows (fused bf16 kernel only): yhat holds ctl[0] compacted
+    const int32_t* live_ctl;   /* optional DEVICE int[8] from c1v_live_rows (fused bf16 kernel only): yhat holds ctl[0] compacted
                                   rows; the grid of (m_pad/128) x splits workgroups is re-dealt on the device to ctl[1] row tiles
                                   x ctl[2] vocabulary splits, so ut must hold max_splits slabs (see c1v_live_rows) */
     int32_t ut_dtype;          /* C1V_F32 (default) or C1V_BF16: element type of the `ut` slabs.  bf16 slabs halve the bytes the
@@ -312,9 +312,15 @@ int c1v_cos_softmax_finish(const c1v_xent_finish_args*, void* stream);
 /* Rows without a target (ids[m] < 0: padding behind the end of a text) contribute exactly zero to the loss and to its
  * gradient (reference :1199-1201 multiplies by the mask), so the loss stages may run on the compacted live rows only:
  *   pos[m] = index of row m among the rows with ids[m] >= 0, or -1
- *   ctl[0] = n_live, ctl[1] = ceil(n_live/128) row tiles, ctl[2] = vocabulary splits per row tile
- *            = clamp(items / ctl[1], 1, min(max_splits, vocab_tiles)), ctl[3] = ceil(vocab_tiles / ctl[2])
- * `items` = workgroups of the c1v_cos_softmax_accum grid = (m_pad/128) * splits; vocab_tiles = n_pad/64. */
+ *   ctl (DEVICE int[8]):
+ *   ctl[0] = n_live, ctl[1] = ceil(n_live/128) row tiles,
+ *   ctl[4] = FULL row tiles = the largest multiple of 256 (one workgroup per CU) <= ctl[1]: each takes the whole vocabulary
+ *            in ONE workgroup (slab 0 of ut),
+ *   ctl[2] = vocabulary splits of each of the remaining ctl[1] - ctl[4] row tiles, chosen so that they make up one more
+ *            round of workgroups: clamp((ctl[4] ? 256 : items) / remaining, 1, min(max_splits, vocab_tiles)),
+ *   ctl[3] = ceil(vocab_tiles / ctl[2])
+ * `items` = workgroups of the c1v_cos_softmax_accum grid = (m_pad/128) * splits >= ctl[4] + remaining * ctl[2];
+ * vocab_tiles = n_pad/64. */
 int c1v_live_rows(const int32_t* ids, int32_t M, int32_t items, int32_t vocab_tiles, int32_t max_splits, int32_t* pos, int32_t* ctl, void* stream);
 typedef struct c1v_live_rows_args { const int32_t* ids; int32_t M, items, vocab_tiles, max_splits; int32_t* pos; int32_t* ctl; } c1v_live_rows_args;
 int c1v_cos_softmax_xent_fwd(const c1v_xent_accum_args*, void* stream);   /* need_u = 0 alias */
