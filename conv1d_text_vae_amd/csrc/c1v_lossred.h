@@ -76,47 +76,70 @@ constexpr int VS_CUS = 256;       // compute units of an MI355X: workgroups of t
 // there are fewer than VS_CUS -- is cut into as many vocabulary splits as make up one more round, so that the last round
 // is as short as its share of the work (1051 row tiles: 4 rounds + 27 tiles x 9 splits, instead of a fifth whole round
 // for 27 workgroups).
-// One workgroup of any whole number of waves <= 16 (also run as a block of c1v_step_prologue): every thread owns a run of
-// consecutive rows (a multiple of 4, read and written as 16-byte words), the runs are scanned through LDS.
+// One workgroup of any whole number of waves <= 16 (also run as a block of c1v_step_prologue).  Every WAVE owns a contiguous
+// run of rows and walks it 256 rows at a time -- lane l holds rows 4l .. 4l+3 of the step as one 16-byte word, so loads and
+// stores are whole 1 KB lines -- eight steps per round of requests; the order inside a step comes from a wave scan, the
+// waves' bases from LDS.  (Round 1 gave every THREAD a contiguous run: 64 lanes x 16 bytes 1 KB apart per request and one
+// request per round trip -- at C4, 262 k rows, 0.19 ms for this single block; 43 us now.  A one-pass form that keeps the
+// flags of 128 steps in registers was 36 us alone but its unrolled code cost the C2 prologue 7 us: not kept.)
 __device__ __forceinline__ void live_rows_body(const int* __restrict__ ids, int M, int items, int vocab_tiles, int max_splits,
                                                int* __restrict__ pos, int* __restrict__ ctl) {
     __shared__ int wsum[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x, nwave = nthr >> 6;
-    const int per = ((M + nthr - 1) / nthr + 3) & ~3;
-    const int m0 = tid * per;
+    constexpr int UN = 8;
+    const int per_wave = (((M + nwave - 1) / nwave + 255) / 256) * 256;       // rows per wave: whole 256-row steps
+    const int w0 = wave * per_wave;
     const bool vec = ((((uintptr_t)ids) | ((uintptr_t)pos)) & 15) == 0;
+    auto load4 = [&](int m) -> int4 {                                          // ids of rows m .. m+3 (-1 behind the end)
+        if (vec && m + 3 < M) return *(const int4*)(ids + m);
+        int4 v;
+        v.x = m < M ? ids[m] : -1; v.y = m + 1 < M ? ids[m + 1] : -1; v.z = m + 2 < M ? ids[m + 2] : -1; v.w = m + 3 < M ? ids[m + 3] : -1;
+        return v;
+    };
     int cnt = 0;
-    for (int i = 0; i < per; i += 4) {
-        const int m = m0 + i;
-        if (vec && m + 3 < M) {
-            const int4 v = *(const int4*)(ids + m);
-            cnt += (v.x >= 0) + (v.y >= 0) + (v.z >= 0) + (v.w >= 0);
-        } else {
-            for (int k = 0; k < 4; ++k) cnt += (m + k < M && ids[m + k] >= 0) ? 1 : 0;
-        }
-    }
-    int incl = cnt;                                    // inclusive scan inside the wave
+    for (int s0 = 0; s0 < per_wave && w0 + s0 < M; s0 += 256 * UN) {
+        int4 v[UN];
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
-    if (lane == 63) wsum[wave] = incl;
+        for (int u = 0; u < UN; ++u) v[u] = load4(w0 + s0 + 256 * u + 4 * lane);
+#pragma unroll
+        for (int u = 0; u < UN; ++u)
+            if (s0 + 256 * u < per_wave) cnt += (v[u].x >= 0) + (v[u].y >= 0) + (v[u].z >= 0) + (v[u].w >= 0);
+    }
+    int incl = cnt;                                    // the wave's total, in every lane
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) incl += __shfl_xor(incl, o, 64);
+    if (lane == 0) wsum[wave] = incl;
     __syncthreads();
     int base = 0;
     for (int w = 0; w < wave; ++w) base += wsum[w];
-    int p = base + incl - cnt;
-    for (int i = 0; i < per; i += 4) {
-        const int m = m0 + i;
-        if (vec && m + 3 < M) {
-            const int4 v = *(const int4*)(ids + m);
-            int4 o;
-            o.x = v.x >= 0 ? p++ : -1; o.y = v.y >= 0 ? p++ : -1; o.z = v.z >= 0 ? p++ : -1; o.w = v.w >= 0 ? p++ : -1;
-            *(int4*)(pos + m) = o;
-        } else {
-            for (int k = 0; k < 4; ++k)
-                if (m + k < M) pos[m + k] = ids[m + k] >= 0 ? p++ : -1;
+    int run = base;                                    // compact index of the wave's next live row
+    for (int s0 = 0; s0 < per_wave && w0 + s0 < M; s0 += 256 * UN) {
+        int4 v[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) v[u] = load4(w0 + s0 + 256 * u + 4 * lane);
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            if (s0 + 256 * u >= per_wave) continue;
+            const int m = w0 + s0 + 256 * u + 4 * lane;
+            const int c = (v[u].x >= 0) + (v[u].y >= 0) + (v[u].z >= 0) + (v[u].w >= 0);
+            int sc = c;                                // inclusive scan over the lanes
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(sc, o, 64); if (lane >= o) sc += t; }
+            int p = run + sc - c;
+            run += __shfl(sc, 63, 64);
+            int4 o4;
+            o4.x = v[u].x >= 0 ? p++ : -1; o4.y = v[u].y >= 0 ? p++ : -1; o4.z = v[u].z >= 0 ? p++ : -1; o4.w = v[u].w >= 0 ? p++ : -1;
+            if (vec && m + 3 < M) *(int4*)(pos + m) = o4;
+            else {
+                if (m < M) pos[m] = o4.x;
+                if (m + 1 < M) pos[m + 1] = o4.y;
+                if (m + 2 < M) pos[m + 2] = o4.z;
+                if (m + 3 < M) pos[m + 3] = o4.w;
+            }
         }
     }
     if (tid == nthr - 1) {
-        const int live = base + incl;
+        const int live = base + incl;          // (last wave: its base + its total)
         const int tiles = (live + VS_BM_ROWS - 1) / VS_BM_ROWS;
         int full = (tiles / VS_CUS) * VS_CUS;
         if (full > items) full = (items / VS_CUS) * VS_CUS;   // (cannot happen with a grid that covers all row tiles)
