@@ -873,8 +873,10 @@ template <int BM, int BN, int NS> constexpr int nt_lds() {
 }
 static inline int64_t nt_large_tiles() {
     // (diagnostic / test override: the tile count from which the large-GEMM variant is taken)
+    // (default: measured per layer at C4, profiles/r02b_c4_gemm_variant_threshold.txt -- from one tile per CU on, two
+    // co-resident workgroups with shallow rings beat one with a deep ring; round 1 started at 768)
     const char* env = getenv("C1V_NT_LARGE_TILES");
-    return env ? atoll(env) : 768;
+    return env ? atoll(env) : 256;
 }
 static inline int nt_large_ns() {
     // ring depth of the large-GEMM variant: 2 stages = 64 KiB = two workgroups per CU; 4 / 5 stages = one workgroup per CU
@@ -892,7 +894,7 @@ static inline NtVariant nt_variant(const NtParams& p) {
     // small) keep the small-GEMM variants.
     const int64_t tiles128 = c1v_cdiv(p.e.M, 128) * c1v_cdiv(p.e.N, 128);
     if (p.ksplits <= 1 && p.e.row_mode != C1V_ROW_LATENT_BWD && tiles128 >= nt_large_tiles()) return NT_128L;
-    return tiles128 >= 384 ? NT_128 : NT_64;
+    return tiles128 >= 384 ? NT_128 : NT_64;      // (NT_128: split-K / latent-head launches of that size, and threshold overrides)
 }
 template <typename K> static void set_lds(K kern, int bytes) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
