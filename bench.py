@@ -361,7 +361,8 @@ def predict_c5_leg(dev, dtype, world, rank, dist=None, steps=3):
     eng.load_batch(x=x)
     M = B * T
     lib = L.load()
-    if world > 1:
+    exchange = dist is not None          # (also at world size 1 under --rehearse-multi: the same calls, one shard)
+    if exchange:
         all_s = torch.empty((world, M), dtype=torch.float32, device=dev)
         all_i = torch.empty((world, M), dtype=torch.int32, device=dev)
         out_s = torch.empty(M, dtype=torch.float32, device=dev)
@@ -371,7 +372,7 @@ def predict_c5_leg(dev, dtype, world, rank, dist=None, steps=3):
         post = eng.reconstruct(postprocess=True)
         dec.load_rows_normalized(post, V - 1)
         s, i = dec.run()
-        if world == 1:
+        if not exchange:
             return s, i
         dist.all_gather_into_tensor(all_s, s.contiguous())
         dist.all_gather_into_tensor(all_i, i.contiguous())
@@ -404,7 +405,7 @@ def predict_c5_leg(dev, dtype, world, rank, dist=None, steps=3):
             'n_gpus': world, 'vocab_words_total': n_total, 'vocab_words_per_gpu': end - begin,
             'workload': 'C5: batch 512, seq_len 256, emb 300, vocabulary sharded by rows (250000 words per GPU; 2M on 8 GPUs): '
                         'encoder+decoder+EOS truncation+per-shard GEMM/arg-max' +
-                        ('+RCCL all-gather of (score, index)+merge' if world > 1 else ' (one shard, no exchange at 1 GPU)'),
+                        ('+RCCL all-gather of (score, index)+merge' if exchange else ' (one shard, no exchange at 1 GPU)'),
             'vocab_argmax_ms': k_ms, 'vocab_argmax_tflops_per_gpu': flops / (k_ms * 1e-3) / 1e12,
             'vocab_argmax_frac_of_peak': flops / (k_ms * 1e-3) / 1e12 / BF16_DENSE_PEAK_TFLOPS}
 
@@ -445,6 +446,9 @@ def main():
     ap.add_argument('--force-dp-path', action='store_true',
                     help='rehearse the multi-rank step sequence (bucketed RCCL all-reduces inside the step graph) at any world size')
     ap.add_argument('--kernel-only', action='store_true', help='only loop the dominant kernel (for rocprofv3 --pmc passes)')
+    ap.add_argument('--rehearse-multi', action='store_true',
+                    help='one GPU, RCCL at world size 1: run exactly the legs and the record of an N > 1 launch (C4 data-parallel '
+                         'step with captured collectives, solo rate, sharded C5 predict with all-gather + merge)')
     ap.add_argument('--dry-run', action='store_true',
                     help='rehearse the launch only (spawn, rendezvous over gloo, one all-reduce, the JSON relay): no GPU work')
     args = ap.parse_args()
@@ -472,7 +476,10 @@ def main():
         if rank == 0:
             print(json.dumps({'metric': 'dry_run', 'n_gpus': world, 'rank_sum': total}), flush=True)
         return
-    cfg_name = args.config or ('c2' if world == 1 else 'c4')
+    if args.rehearse_multi:
+        args.force_dp_path = True
+    multi = world > 1 or args.rehearse_multi
+    cfg_name = args.config or ('c4' if multi else 'c2')
     torch.cuda.set_device(local_rank)
     dev = 'cuda:%d' % local_rank
     dist = None
@@ -493,7 +500,7 @@ def main():
         return
 
     rec = train_leg(cfg_name, args.dtype, dev, world, rank, args.steps, args.warmup, dist, args.force_dp_path,
-                    with_gemm_table=(cfg_name == 'c4' and world == 1))
+                    with_gemm_table=(cfg_name == 'c4' and not multi))
     out = None
     if rank == 0:
         out = {'metric': 'train_sequences_per_sec', 'value': rec['value'], 'unit': 'sequences/s', 'n_gpus': world,
@@ -503,7 +510,7 @@ def main():
         for k in ('gemm_rooflines', 'roofline_conv'):
             if k in rec:
                 out[k] = rec[k]
-    if world > 1:
+    if multi:
         # the same per-GPU workload WITHOUT the collectives, all ranks at once: the one-GPU rate a scaling figure for this
         # workload has to be taken against (the N = 1 line of this benchmark is C2, not C4; its `c4` sub-record is this too)
         solo = train_leg(cfg_name, args.dtype, dev, 1, 0, max(5, args.steps // 4), 3, None, False)
