@@ -104,6 +104,41 @@ def test_train_forward_backward_parity(name, dtype):
             assert rel_err(g[k_], ref) < 0.3, (k_, rel_err(g[k_], ref))
 
 
+def test_stream_kernel_whole_rounds_plus_split_remainder(monkeypatch):
+    """More live row tiles than CUs (the C4 regime, here with a toy model: 1400 samples x 64 steps, ~350 live row tiles):
+    c1v_live_rows deals the first 256 row tiles one workgroup each over the whole vocabulary and cuts the remainder into
+    vocabulary splits (ctl[4], ctl[2]); the finish step sums one slab for the former and ctl[2] for the latter.  Loss,
+    per-sample cross-entropy and the decoder-side gradients against the fp64 oracle, and against the same engine without
+    the live-row compaction (static grid, every row through the kernel)."""
+    c = dict(B=1400, T_in=20, T_out=64, E=30, n_filters=(8,), k=3, D=4, N=320)
+    og, params, Wv, x, ids, eps, mask_e, mask_d = make_case(c)
+    p64 = {k: v.astype(np.float64) for k, v in params.items()}
+    loss, grads, acts = O.train_forward_backward(og, p64, Wv.astype(np.float64), x.astype(np.float64), ids,
+                                                 eps.astype(np.float64), mask_e, mask_d)
+    res = {}
+    for live in ('1', '0'):
+        monkeypatch.setenv('C1V_LIVE_ROWS', live)
+        eng = build_engine(c, og, params, Wv, 'bf16')
+        load_fixed(eng, x, ids, eps, mask_e, mask_d)
+        eng._run(eng.train_ops(False))
+        torch.cuda.synchronize()
+        if live == '1':
+            ctl = eng.live_ctl.cpu().numpy()
+            n_live = int((ids >= 0).sum())
+            assert ctl[0] == n_live and ctl[1] == -(-n_live // 128)
+            assert ctl[1] > 256, 'the case must have more live row tiles than CUs'
+            assert ctl[4] == 256 and ctl[2] >= 2, ctl
+            assert ctl[4] + (ctl[1] - ctl[4]) * ctl[2] <= (eng.m_pad // 128) * eng.x_splits
+        res[live] = (eng.loss(), eng.xent_b.cpu().numpy(), eng.get_grads())
+    for live, (l, xb, g) in res.items():
+        assert abs(l - loss) < 1e-2 * max(1.0, abs(loss)), (live, l, loss)
+        np.testing.assert_allclose(xb, acts['xent_b'], rtol=1e-2, atol=1e-2)
+        for k_ in ('deconv_decoder_embeddings/kernel', 'deconv_decoder_embeddings/bias'):
+            assert rel_l2(g[k_], grads[k_]) < 2e-2, (live, k_, rel_l2(g[k_], grads[k_]))
+    assert abs(res['1'][0] - res['0'][0]) < 2e-3 * max(1.0, abs(loss))
+    np.testing.assert_allclose(res['1'][1], res['0'][1], rtol=5e-3, atol=5e-3)
+
+
 @pytest.mark.parametrize('name', ['tiny1', 'deep3', 'k4', 'mid', 'kp192', 'big128'])
 @pytest.mark.parametrize('dtype', ['f32', 'bf16'])
 def test_large_gemm_variant_parity(name, dtype, monkeypatch):

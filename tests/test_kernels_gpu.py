@@ -110,6 +110,17 @@ def test_eos_truncate_known_answers():
     np.testing.assert_allclose(out.cpu().numpy(), true, atol=1e-6)
     np.testing.assert_allclose(out.cpu().numpy(), O.postprocess_reconstructed_word_vectors(src), atol=1e-6)
     assert np.array_equal(end.cpu().numpy(), O.eos_end_index(src))
+    # the same rows lying `ldy` values apart (the engine pads the decoder output's rows to 32 bytes): bit-identical
+    ldy = 16
+    wide = np.full((B, T, ldy), 7.0, dtype=np.float32)          # (the padding holds values that would win the arg-max)
+    wide[:, :, :V] = src
+    y2 = torch.from_numpy(wide).cuda()
+    out2 = torch.zeros(B, T, V - 1, device='cuda')
+    end2 = torch.zeros(B, dtype=torch.int32, device='cuda')
+    L.check(lib.c1v_eos_truncate_normalize_ld(y2.data_ptr(), ldy, B, T, V, out2.data_ptr(), end2.data_ptr(), _stream()))
+    assert np.array_equal(out2.cpu().numpy(), out.cpu().numpy(), equal_nan=True)
+    assert np.array_equal(end2.cpu().numpy(), end.cpu().numpy())
+    assert lib.c1v_eos_truncate_normalize_ld(y2.data_ptr(), V - 1, B, T, V, out2.data_ptr(), end2.data_ptr(), _stream()) != 0
 
 
 # ------------------------------------------------------------------------------------------------ RNG

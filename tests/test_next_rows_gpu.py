@@ -64,6 +64,14 @@ def test_gather_input_equals_the_reference_batch_generator(dtype):
         # the one-hot target of the reference generator <-> the int32 ids the loss kernels take
         want_ids = np.where(y_ref.any(axis=2), y_ref.argmax(axis=2), -1)
         assert np.array_equal(out_ids, want_ids)
+        if idx == 0:
+            # a table whose rows are NOT whole 16-byte words (ld = V + 1, odd): the element-wise path of the kernel
+            tab2 = torch.zeros(table.shape[0], V + 1, dtype=torch.float32, device='cuda')
+            tab2[:, :V] = torch.from_numpy(table)
+            a2 = L.GatherInputArgs(tab2.data_ptr(), V + 1, eng.in_ids.data_ptr(), T_in, V, eng.Xe[0].seq())
+            eng.Xe[0].t.fill_(7.0)
+            L.check(lib.c1v_gather_input(C.byref(a2), _stream()), 'c1v_gather_input')
+            assert np.array_equal(eng.Xe[0].valid().float().cpu().numpy(), want)
     # a train step fed from ids is the train step fed from the dense batch, to the bit
     x_ref, _ = seq[1]
     in_ids, out_ids = seq.ids(1)
