@@ -208,6 +208,7 @@ SYMBOLS = {
     'c1v_latent_head_bwd': ([_P(LatentArgs), C.c_void_p], C.c_int),
     'c1v_l2norm_rows': ([_P(L2NormArgs), C.c_void_p], C.c_int),
     'c1v_live_rows': ([C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p], C.c_int),
+    'c1v_live_rows_gather': ([_P(LiveRowsArgs), _P(GatherInputArgs), C.c_void_p], C.c_int),
     'c1v_cos_softmax_accum': ([_P(XentAccumArgs), C.c_void_p], C.c_int),
     'c1v_cos_softmax_xent_fwd': ([_P(XentAccumArgs), C.c_void_p], C.c_int),
     'c1v_cos_softmax_xent_bwd': ([_P(XentAccumArgs), C.c_void_p], C.c_int),

@@ -799,6 +799,37 @@ extern "C" int c1v_philox_multi(const c1v_rng_desc* descs, int32_t n_desc, int32
     return 0;
 }
 
+// Large batches (see VAEEngine._input_own_launch): the live-row table and the encoder operand in ONE launch of 1024-thread
+// blocks -- block 0 scans the targets with 16 waves, the others assemble the input; neither needs the other's result.
+struct LiveGatherDev {
+    const int* ids; int M, items, vocab_tiles, max_splits; int* pos; int* ctl;
+    const float* table; int64_t ld; const int* in_ids; int T, C; c1v_seq dst; int in_blocks, in_dtype;
+};
+__global__ __launch_bounds__(1024) void live_gather_kernel(const LiveGatherDev d) {
+    if (blockIdx.x == 0) { live_rows_body(d.ids, d.M, d.items, d.vocab_tiles, d.max_splits, d.pos, d.ctl); return; }
+    const int blk = (int)blockIdx.x - 1;
+    if (d.in_dtype == C1V_F32) gather_input_body<float>(d.table, d.ld, d.in_ids, d.T, d.C, d.dst, blk, d.in_blocks);
+    else gather_input_body<bf16_raw>(d.table, d.ld, d.in_ids, d.T, d.C, d.dst, blk, d.in_blocks);
+}
+extern "C" int c1v_live_rows_gather(const c1v_live_rows_args* l, const c1v_gather_input_args* a, void* stream) {
+    C1V_REQUIRE(l && a, "live_rows_gather: null argument");
+    C1V_REQUIRE(l->ids && l->pos && l->ctl && l->M > 0 && l->items > 0 && l->vocab_tiles > 0 && l->max_splits > 0, "live_rows_gather: bad live-row argument");
+    C1V_REQUIRE(l->items >= (int)c1v_cdiv(l->M, VS_BM_ROWS), "live_rows_gather: the stream grid must cover all row tiles");
+    C1V_REQUIRE(a->table && a->ids, "live_rows_gather: null gather argument");
+    if (check_seq(a->dst, "live_rows_gather dst")) return -1;
+    C1V_REQUIRE(a->T > 0 && a->T <= a->dst.len && a->C > 0 && a->C <= a->dst.cp && a->ld >= a->C, "live_rows_gather: shape mismatch");
+    C1V_REQUIRE(a->dst.cp % 8 == 0 && a->dst.bstride % 8 == 0 && ((uintptr_t)a->dst.data % 32) == 0, "live_rows_gather: dst rows must be 8-element groups, 32-byte aligned");
+    LiveGatherDev d{};
+    d.ids = l->ids; d.M = l->M; d.items = l->items; d.vocab_tiles = l->vocab_tiles; d.max_splits = l->max_splits; d.pos = l->pos; d.ctl = l->ctl;
+    d.table = a->table; d.ld = a->ld; d.in_ids = a->ids; d.T = a->T; d.C = a->C; d.dst = a->dst; d.in_dtype = a->dst.dtype;
+    const int64_t total = (int64_t)a->dst.batch * a->T * (a->dst.cp / 8);
+    int64_t nb = c1v_cdiv(total, 1024 * 4);                        // ~4 eight-element groups per thread
+    d.in_blocks = (int)(nb < 1 ? 1 : (nb > 4096 ? 4096 : nb));
+    hipLaunchKernelGGL(live_gather_kernel, dim3((unsigned)(1 + d.in_blocks)), dim3(1024), 0, (hipStream_t)stream, d);
+    C1V_LAUNCH_CHECK();
+    return 0;
+}
+
 // device-side step counter used by captured graphs (RNG offsets advance without host involvement)
 __global__ void counter_add_kernel(uint64_t* ctr, uint64_t inc) { if (threadIdx.x == 0 && blockIdx.x == 0) ctr[0] += inc; }
 extern "C" int c1v_counter_add(uint64_t* ctr, uint64_t inc, void* stream) {

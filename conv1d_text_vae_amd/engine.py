@@ -1049,6 +1049,19 @@ class VAEEngine:
     def _fused_prologue(self) -> bool:
         return os.environ.get('C1V_PROLOGUE', '1') == '1'
 
+    def _live_gather_op(self):
+        """c1v_live_rows + c1v_gather_input in one launch of 1024-thread blocks (large batches)."""
+        if getattr(self, '_live_gather_cached', None) is None or self._live_gather_cached[0] is not self._gather_args:
+            if self.ops_gather_in is None:
+                raise L.C1VError('from_ids=True needs set_input_table() first')
+            f = self.lib.c1v_live_rows_gather
+            la, ga = self._live_args, self._gather_args
+
+            def run():
+                L.check(f(C.byref(la), C.byref(ga), self._stream()), 'c1v_live_rows_gather')
+            self._live_gather_cached = (ga, run)
+        return self._live_gather_cached[1]
+
     def _input_own_launch(self) -> bool:
         """A large batch (C4: a 168 MB encoder operand, 262 k target rows) takes the input assembly and the live-row table
         out of the prologue into launches of their own: the prologue kernel runs 256-thread blocks, so its single
@@ -1071,7 +1084,12 @@ class VAEEngine:
     def forward_ops(self, with_rng: bool, from_ids: bool = False, advance: bool = False):
         """advance: the step ends in update_ops() (the fused prologue then also prepares the Nadam schedule)."""
         if self._fused_prologue():
-            own_in = (self.ops_live_rows + self._in_ops(from_ids)) if self._input_own_launch() else []
+            if not self._input_own_launch():
+                own_in = []
+            elif from_ids and self.compact:
+                own_in = [self._live_gather_op()]
+            else:
+                own_in = self.ops_live_rows + self._in_ops(from_ids)
             return [self._prologue_op(with_rng, from_ids, advance)] + own_in + self.ops_enc_train + self.ops_lat_train + \
                 self.ops_dec_train + self.ops_loss_train_core
         return (self.ops_rng if with_rng else []) + self._in_ops(from_ids) + self.ops_enc_train + self.ops_lat_train + \

@@ -323,6 +323,9 @@ int c1v_cos_softmax_finish(const c1v_xent_finish_args*, void* stream);
  * vocab_tiles = n_pad/64. */
 int c1v_live_rows(const int32_t* ids, int32_t M, int32_t items, int32_t vocab_tiles, int32_t max_splits, int32_t* pos, int32_t* ctl, void* stream);
 typedef struct c1v_live_rows_args { const int32_t* ids; int32_t M, items, vocab_tiles, max_splits; int32_t* pos; int32_t* ctl; } c1v_live_rows_args;
+/* c1v_live_rows + c1v_gather_input as ONE launch (no counterpart in the reference: two independent jobs of a large batch's
+ * step; block 0 builds the live-row table with 16 waves, the other blocks assemble the encoder operand) */
+int c1v_live_rows_gather(const c1v_live_rows_args* live, const c1v_gather_input_args* gather, void* stream);
 int c1v_cos_softmax_xent_fwd(const c1v_xent_accum_args*, void* stream);   /* need_u = 0 alias */
 int c1v_cos_softmax_xent_bwd(const c1v_xent_accum_args*, void* stream);   /* need_u = 1 alias */
 

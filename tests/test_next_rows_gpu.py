@@ -64,6 +64,17 @@ def test_gather_input_equals_the_reference_batch_generator(dtype):
         # the one-hot target of the reference generator <-> the int32 ids the loss kernels take
         want_ids = np.where(y_ref.any(axis=2), y_ref.argmax(axis=2), -1)
         assert np.array_equal(out_ids, want_ids)
+        if idx == 0 and eng.compact:
+            # the one-launch form for large batches (live-row table + gather, 1024-thread blocks): the same bits as the two
+            eng.load_batch(ids=out_ids)
+            eng.ops_live_rows[0]()
+            torch.cuda.synchronize()
+            pos0, ctl0 = eng.row_pos.clone(), eng.live_ctl.clone()
+            eng.row_pos.fill_(-7); eng.live_ctl.zero_(); eng.Xe[0].t.fill_(7.0)
+            eng._live_gather_op()()
+            torch.cuda.synchronize()
+            assert torch.equal(eng.row_pos, pos0) and torch.equal(eng.live_ctl, ctl0)
+            assert np.array_equal(eng.Xe[0].valid().float().cpu().numpy(), want)
         if idx == 0:
             # a table whose rows are NOT whole 16-byte words (ld = V + 1, odd): the element-wise path of the kernel
             tab2 = torch.zeros(table.shape[0], V + 1, dtype=torch.float32, device='cuda')
