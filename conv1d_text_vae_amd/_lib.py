@@ -54,7 +54,7 @@ class WgradArgs(C.Structure):
                 ('dtype', C.c_int32), ('r_begin', C.c_int64), ('r_end', C.c_int64), ('a_shift0', C.c_int32),
                 ('taps', C.c_int32), ('flip', C.c_int32), ('tap_stride', C.c_int64), ('si', C.c_int64),
                 ('sj', C.c_int64), ('out', C.c_void_p), ('slab_stride', C.c_int64), ('splits', C.c_int32),
-                ('bias_out', C.c_void_p), ('bias_slab_stride', C.c_int64)]
+                ('bias_out', C.c_void_p), ('bias_slab_stride', C.c_int64), ('tap_group', C.c_int32)]
 
 
 class BwdPairArgs(C.Structure):

@@ -2,6 +2,7 @@
 // engine of c1v_gemm.hip, plus error / version / device-info plumbing.  Every shape is checked here, on the host,
 // before anything is launched.
 #include <stdarg.h>
+#include <stdlib.h>
 #include "c1v_common.h"
 
 static thread_local std::string g_err;
@@ -50,7 +51,7 @@ static int conv_params(const c1v_conv1d_args* a, const char* what, NtParams& p) 
     // every window read must stay inside the allocation: the last sample may run into the slack rows
     C1V_REQUIRE(a->a_off + a->n_rows + a->k - 1 <= pitch + C1V_SLACK_ROWS, "%s: window (a_off=%d n_rows=%d k=%d) overruns the sample pitch %d", what, a->a_off, a->n_rows, a->k, pitch);
     const bool pairs = a->epi.row_mode == C1V_ROW_POOL2 || a->epi.row_mode == C1V_ROW_PAIRSUM;
-    const int Le = pairs ? ((a->n_rows + 1) & ~1) : a->n_rows;
+    int Le = pairs ? ((a->n_rows + 1) & ~1) : a->n_rows;
     C1V_REQUIRE(a->a_off + Le + a->k - 1 <= pitch + C1V_SLACK_ROWS, "%s: padded row enumeration overruns the sample pitch", what);
     const int es = c1v_esize(a->x.dtype);
     p = NtParams{};
@@ -58,9 +59,38 @@ static int conv_params(const c1v_conv1d_args* a, const char* what, NtParams& p) 
     p.W = (const char*)a->w_op; p.ldw_b = a->ldw * es; p.Kb = (int64_t)a->k * a->x.cp * es;
     C1V_REQUIRE(a->ldw >= (int64_t)a->k * a->x.cp, "%s: ldw (%lld) is smaller than k*cp", what, (long long)a->ldw);
     if (a->k > 1 && ((int64_t)a->x.cp * es) % 128 == 0) { p.k_taps = a->k; p.k_strips = (int)((int64_t)a->x.cp * es / 128); }
-    const int64_t M = (int64_t)a->x.batch * Le;
+    int64_t M = (int64_t)a->x.batch * Le;
+    // Large convolutions: the wide variant (ntw_body) enumerates the FLAT buffer rows (Le = sample pitch; the rows between
+    // the samples are computed and dropped by the epilogue) so that a tile's activation rows are one contiguous window,
+    // fetched once per channel strip for all taps.  OPT-IN (C1V_NTW=1: whenever it applies; C1V_NTW=auto: when the launch
+    // fills the chip with 256 x 128 tiles and at most `1 - fill` of the enumerated rows are such gaps): measured at C4
+    // (profiles/r03_c4_ntw_stamps.txt) its K loop runs at 54 % MFMA utilisation against ~30 % for the 128 x 128 kernel, but with
+    // one 256-row workgroup per CU the epilogues of all CUs fall together -- an HBM write burst nothing overlaps (19-38 k
+    // cycles per tile) -- and 4.06 rounds of tiles take 5; the two-workgroups-per-CU kernel hides both and is faster overall.
+    if (p.k_taps >= 2 && a->k <= 9 && pitch % 2 == 0 && a->x.bstride == (int64_t)pitch * a->x.cp &&
+        a->epi.row_mode != C1V_ROW_LATENT_BWD) {
+        const char* env = getenv("C1V_NTW");
+        const char* env_t = getenv("C1V_NTW_MIN_TILES");
+        const char* env_f = getenv("C1V_NTW_MIN_FILL");
+        const int64_t Mf = (int64_t)a->x.batch * pitch;
+        const int64_t tiles = c1v_cdiv(Mf, 256) * c1v_cdiv(a->n_out, 128);
+        const bool force = env && env[0] == '1', off = env && env[0] == '0';
+        const double fill = (double)a->n_rows / (double)pitch;
+        const bool automatic = env && env[0] == 'a';        // C1V_NTW=auto: by size (see below why that is not the default)
+        if (!off && Mf < (1ll << 31) && (force || (automatic && tiles >= (env_t ? atoll(env_t) : 224) && fill >= (env_f ? atof(env_f) : 0.70)))) {
+            p.wide = 1;
+            Le = pitch;
+            M = Mf;
+        }
+    }
     C1V_REQUIRE(M < (1ll << 31), "%s: too many rows", what);
-    return c1v_fill_epi(a->epi, p.e, (int)M, Le, a->n_rows, a->n_out);
+    if (c1v_fill_epi(a->epi, p.e, (int)M, Le, a->n_rows, a->n_out)) return -1;
+    if (p.wide && p.e.fastw != 4) {                      // the wide variant only comes with the 4-wide vector epilogue
+        p.wide = 0;
+        Le = pairs ? ((a->n_rows + 1) & ~1) : a->n_rows;
+        return c1v_fill_epi(a->epi, p.e, (int)((int64_t)a->x.batch * Le), Le, a->n_rows, a->n_out);
+    }
+    return 0;
 }
 static int conv_common(const c1v_conv1d_args* a, void* stream, const char* what) {
     NtParams p;
@@ -122,6 +152,9 @@ static int wgrad_params(const c1v_wgrad_args* a, TnParams& p) {
     p.a_shift0 = a->a_shift0; p.taps = a->taps; p.flip = a->flip; p.tap_stride = a->tap_stride; p.si = a->si; p.sj = a->sj;
     p.out = a->out; p.slab_stride = a->slab_stride; p.splits = a->splits;
     p.bias_out = a->bias_out; p.bias_slab_stride = a->bias_slab_stride;
+    C1V_REQUIRE(a->tap_group >= 0 && a->tap_group <= 3, "wgrad: tap_group must be 0..3");
+    p.tg = (a->tap_group >= 2 && a->taps >= 2) ? a->tap_group : 0;
+    C1V_REQUIRE(p.tg == 0 || a->taps % p.tg == 0, "wgrad: tap_group (%d) must divide taps (%d)", a->tap_group, a->taps);
     return 0;
 }
 extern "C" int c1v_wgrad(const c1v_wgrad_args* a, void* stream) {

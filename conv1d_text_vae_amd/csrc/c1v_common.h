@@ -121,6 +121,7 @@ struct NtParams {
     // both operands' rows: the taps of one strip are consecutive tiles, and tap j + 1 re-reads the lines tap j has just
     // fetched (the same buffer rows, shifted by one) while they are still in the XCD's L2.  k_taps <= 1: natural order.
     int k_taps, k_strips;
+    int wide;                                                         // ntw_body: 256 x 128 tiles over the flat buffer rows (e.Le = sample pitch)
     EpiDev e;
 };
 
@@ -131,6 +132,7 @@ struct TnParams {
     int a_shift0; int taps; int flip; int64_t tap_stride, si, sj;
     float* out; int64_t slab_stride; int splits;
     float* bias_out; int64_t bias_slab_stride;
+    int tg;                                          // 0: one workgroup per tap (tn_body); 2 / 3: taps fused (tn_taps_body)
 };
 
 int c1v_launch_nt(int dtype, const NtParams& p, hipStream_t st);

@@ -16,9 +16,35 @@ __global__ __launch_bounds__(C1V_GEMM_THREADS, 3) void gemm_nt_large_kernel(cons
     xcd_tile(blockIdx.x, (p.e.M + 127) >> 7, (p.e.N + 127) >> 7, bx, by);
     nt_body<T, 128, 128, NS, false>(p, bx, by, blockIdx.x, 0);
 }
+// wide variant (ntw_body): a linear grid dealt to (row tile, column tile) by xcd_tile(), one workgroup per CU
+template <typename T, int MODE>
+__global__ __launch_bounds__(C1V_GEMM_THREADS) void gemm_ntw_kernel(const NtParams p) {
+    c1v_touch_kernarg<4>();
+    int bx, by;
+    xcd_tile(blockIdx.x, (p.e.M + NTW_BM - 1) / NTW_BM, (p.e.N + NTW_BN - 1) / NTW_BN, bx, by);
+    ntw_body<T, MODE>(p, bx, by);
+}
 template <typename T>
 __global__ __launch_bounds__(C1V_GEMM_THREADS) void gemm_tn_kernel(const TnParams p) {
     tn_body<T>(p, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// Fused-tap wgrad: a linear grid, dealt to (tile, tap group, row split) so that the workgroups which read the SAME rows --
+// the 128 x 128 tiles and tap groups of one row split -- are dispatched back to back to ONE XCD (workgroups go to the XCDs
+// round-robin; XCD k = id % 8 owns the row splits k, k + 8, ...) and share its L2 copy of both operands.  With the plain
+// 3-d grid the tiles of a split landed on different XCDs and every one of them fetched its rows from HBM again: measured
+// at C4 (rocprofv3 FETCH_SIZE per launch), 2-4 x the operand bytes, at 4.0-4.6 TB/s -- the launches were HBM-bound on re-reads.
+template <typename T, int TG>
+__global__ __launch_bounds__(C1V_GEMM_THREADS) void gemm_tn_taps_kernel(const TnParams p, const int gi, const int gj, const int groups) {
+    const int per_split = gi * gj * groups;
+    const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
+    const int split = xcd + 8 * (slot / per_split);
+    if (split >= p.splits) return;                       // (the grid is rounded up to whole rounds of 8 splits)
+    int r = slot % per_split;
+    const int tgi = r / (gi * gj);
+    r -= tgi * gi * gj;
+    const int by = r / gi, bx = r - by * gi;
+    tn_taps_body<T, TG>(p, bx, by, tgi * p.splits + split);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -46,7 +72,27 @@ template <typename T> static void launch_nt_large(const NtParams& p, hipStream_t
     }
 }
 
+template <typename T, int MODE> static void launch_ntw_m(const NtParams& p, hipStream_t st) {
+    static bool once = (set_lds(gemm_ntw_kernel<T, MODE>, NTW_LDS), true); (void)once;
+    dim3 grid((unsigned)(c1v_cdiv(p.e.M, NTW_BM) * c1v_cdiv(p.e.N, NTW_BN)), 1, 1);
+    hipLaunchKernelGGL((gemm_ntw_kernel<T, MODE>), grid, dim3(C1V_GEMM_THREADS), NTW_LDS, st, p);
+}
+template <typename T> static void launch_ntw(const NtParams& p, hipStream_t st) {
+    switch (p.e.row_mode) {
+        case C1V_ROW_STORE:   launch_ntw_m<T, C1V_ROW_STORE>(p, st); break;
+        case C1V_ROW_POOL2:   launch_ntw_m<T, C1V_ROW_POOL2>(p, st); break;
+        case C1V_ROW_UP2:     launch_ntw_m<T, C1V_ROW_UP2>(p, st); break;
+        case C1V_ROW_PAIRSUM: launch_ntw_m<T, C1V_ROW_PAIRSUM>(p, st); break;
+        default:              launch_ntw_m<T, C1V_ROW_UNPOOL>(p, st); break;
+    }
+}
+
 template <typename T> static int launch_nt_t(const NtParams& p, hipStream_t st) {
+    if (p.wide) {
+        launch_ntw<T>(p, st);
+        C1V_LAUNCH_CHECK();
+        return 0;
+    }
     switch (nt_variant(p)) {
         case NT_128L:    launch_nt_large<T>(p, st); break;
         case NT_128:     launch_nt_v<T, 128, 128, 3>(p, st); break;
@@ -64,6 +110,11 @@ int c1v_check_nt(const NtParams& p) {
                 (long long)p.ldw_b, (long long)p.Kb);
     const bool pairs = p.e.row_mode == C1V_ROW_POOL2 || p.e.row_mode == C1V_ROW_PAIRSUM;
     C1V_REQUIRE(!pairs || (p.e.Le % 2 == 0), "pair epilogue needs an even row enumeration (Le=%d)", p.e.Le);
+    if (p.wide)
+        C1V_REQUIRE(p.k_taps >= 2 && p.k_taps <= 9 && p.k_strips >= 1 && p.Kb == (int64_t)p.k_taps * p.k_strips * 128 && p.ksplits <= 1 &&
+                    p.e.row_mode != C1V_ROW_LATENT_BWD && p.e.fastw == 4,
+                    "wide NT variant: needs a convolution over whole 128-byte channel strips (taps %d, strips %d, K %lld bytes)",
+                    p.k_taps, p.k_strips, (long long)p.Kb);
     if (p.ksplits > 1) {
         C1V_REQUIRE(p.e.row_mode == C1V_ROW_STORE && !p.e.relu && !p.e.exp2 && p.e.act == nullptr && p.e.keep == nullptr,
                     "split-K needs a plain STORE epilogue (partial sums are not final values)");
@@ -84,7 +135,19 @@ int c1v_launch_nt(int dtype, const NtParams& p, hipStream_t st) {
     return dtype == C1V_F32 ? launch_nt_t<float>(p, st) : launch_nt_t<bf16_raw>(p, st);
 }
 
+template <typename T, int TG> static void launch_tn_taps(const TnParams& p, hipStream_t st) {
+    static bool once = (set_lds(gemm_tn_taps_kernel<T, TG>, TNF_LDS), true); (void)once;
+    const int gi = (int)c1v_cdiv(p.I, 128), gj = (int)c1v_cdiv(p.J, 128), groups = (int)c1v_cdiv(p.taps, TG);
+    const int64_t blocks = c1v_cdiv(p.splits, 8) * 8 * gi * gj * groups;
+    hipLaunchKernelGGL((gemm_tn_taps_kernel<T, TG>), dim3((unsigned)blocks), dim3(C1V_GEMM_THREADS), TNF_LDS, st, p, gi, gj, groups);
+}
+
 template <typename T> static int launch_tn_t(const TnParams& p, hipStream_t st) {
+    if (p.tg >= 2) {
+        if (p.tg == 2) launch_tn_taps<T, 2>(p, st); else launch_tn_taps<T, 3>(p, st);
+        C1V_LAUNCH_CHECK();
+        return 0;
+    }
     static bool once = (set_lds(gemm_tn_kernel<T>, TN_LDS), true); (void)once;
     dim3 grid((unsigned)c1v_cdiv(p.I, 128), (unsigned)c1v_cdiv(p.J, 128), (unsigned)(p.taps * p.splits));
     hipLaunchKernelGGL((gemm_tn_kernel<T>), grid, dim3(C1V_GEMM_THREADS), TN_LDS, st, p);

@@ -101,7 +101,7 @@ __device__ __forceinline__ void epilogue_rows(const EpiDev& e, const float* ct, 
             else if (mode == C1V_ROW_UP2) o = o && u < e.nrows && 2 * t < e.dst_len;
             else if (mode == C1V_ROW_UNPOOL) o = o && u < e.nrows && 2 * t + 1 < e.dst_len;
             else if (mode == C1V_ROW_POOL2) o = o && t < e.dst_len && u + 1 < e.nrows;
-            else o = o && t < e.dst_len;
+            else o = o && t < e.dst_len && u < e.nrows;
             ok[jj] = o; bb[jj] = b; uu[jj] = u; tt[jj] = t;
 #pragma unroll
             for (int k = 0; k < 4; ++k) { am[jj][k] = 1.0f; by[jj][k] = 1; }
@@ -305,7 +305,7 @@ __device__ __forceinline__ void epi_load(const EpiDev& e, const RowDiv& rd, EpiS
         else if (MODE == C1V_ROW_UP2) { o = o && u < e.nrows && 2 * t < e.dst_len; f = 2 * t + 1 < e.dst_len ? 2u : 0u; }
         else if (MODE == C1V_ROW_UNPOOL) o = o && u < e.nrows && 2 * t + 1 < e.dst_len;
         else if (MODE == C1V_ROW_POOL2) o = o && t < e.dst_len && u + 1 < e.nrows;
-        else { o = o && t < e.dst_len; f = (u < e.nrows ? 2u : 0u) | (u + 1 < e.nrows ? 4u : 0u); }
+        else { o = o && t < e.dst_len && u < e.nrows; f = (u < e.nrows ? 2u : 0u) | (u + 1 < e.nrows ? 4u : 0u); }
         const int trow = (MODE == C1V_ROW_UP2 || MODE == C1V_ROW_UNPOOL) ? 2 * t : t;
         st.di[jj] = (int64_t)b * e.dst_bstride + (int64_t)(e.dst_off + trow) * e.dst_cp + c;
         st.si[jj] = (int)((int64_t)b * e.sel_bstride + (int64_t)t * e.sel_cp + c);
@@ -701,12 +701,267 @@ __device__ __forceinline__ void nt_body(const NtParams& p, const int bx, const i
 }
 
 // ------------------------------------------------------------------------------------------------------
+// NT kernel of the LARGE convolutions (round 3; `ntw_body`, NtParams::wide): a 256 x 128 tile over the FLAT rows of the
+// activation buffer, the activation window of a 128-byte channel strip fetched ONCE for all taps.
+//
+// Why: at C4's shapes the 128 x 128 kernel above is bound by what a CU takes in from L2, not by its MFMAs -- every K tile
+// (one tap of one strip) brings 16 KiB of activations AND 16 KiB of weights for 512 MFMA cycles (64 B/clk wanted, ~30
+// delivered), and the three taps of a strip fetch the same activation rows three times, one row further down each time.
+// Here the GEMM rows are the buffer rows themselves (NtParams::e.Le = the sample pitch: rows between the samples compute
+// garbage that the epilogue's `u < nrows` tests drop -- a few per cent at the layers this variant is taken for), so the
+// activation rows of a tile are ONE contiguous window: BM + k - 1 rows, loaded once per strip into a ring of its own, and
+// tap j reads its fragments j rows further down.  Per strip a CU then takes in 33 KiB of activations + 3 x 16 KiB of weights
+// for 3 x 1024 MFMA cycles: 27 B/clk at the full MFMA rate instead of 64.
+// Waves 0-3 compute 64 x 128 each (8 fragment reads per 32 MFMAs instead of 8 per 16), waves 4 / 5 feed the window ring /
+// the weight ring.  One barrier per K tile; barrier t also promises that tile t+1 has LANDED, so the first fragments of the
+// next tile are fetched before its barrier and no LDS latency is exposed behind one.  Fragment reads run three groups of
+// four MFMAs ahead of their use (sched_barrier(0) pins the order: with one wave per SIMD nothing else hides LDS latency).
+// Results are bit-identical to nt_body's (same products, same order of the K tiles).
+// ------------------------------------------------------------------------------------------------------
+constexpr int NTW_BM = 256, NTW_BN = 128;
+constexpr int NTW_AROWS = NTW_BM + 8;                  // window rows: the tile's rows + up to 8 rows of halo (k <= 9)
+constexpr int NTW_A_STAGE = NTW_AROWS * 128;
+constexpr int NTW_W_STAGE = NTW_BN * 128;
+constexpr int NTW_NSA = 2, NTW_NSW = 5;
+constexpr int NTW_RING = NTW_NSA * NTW_A_STAGE + NTW_NSW * NTW_W_STAGE;
+constexpr int NTW_LDC = NTW_BN + 4;
+constexpr int NTW_LDS = NTW_RING > NTW_BM * NTW_LDC * 4 ? NTW_RING : NTW_BM * NTW_LDC * 4;
+static_assert(NTW_LDS <= 160 * 1024, "one workgroup per CU");
+
+template <typename T, int MODE>
+__device__ __forceinline__ void ntw_body(const NtParams& p, const int bx, const int by) {
+#ifdef NT_STAMP
+    unsigned long long stamp[16];
+#endif
+    NT_T(0);
+    constexpr int BM = NTW_BM, BN = NTW_BN, MI = 4, NJ = 8;
+    constexpr int IPA = NTW_AROWS / 8, IPW = BN / 8;
+    static_assert(IPA <= 63 && 2 * IPW <= 63, "vmcnt is a 6-bit counter");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const sA = smem;
+    char* const sW = smem + NTW_NSA * NTW_A_STAGE;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m0 = bx * BM, n0 = by * BN;
+    const RowDiv rd = make_rowdiv(m0, p.e.Le);
+    const int taps = p.k_taps, strips = p.k_strips;
+    const int KT = taps * strips;
+    EpiDev ev = p.e;
+
+    if (wave >= 4) {
+        const int prow = lane >> 3, ppos = lane & 7;
+        if (wave == 4) {
+            // ---- activation windows: buffer rows a_off + m0 + [0, NTW_AROWS), clamped into the allocation (rows past the
+            // last sample only feed GEMM rows >= M, which the epilogue drops)
+            const int64_t lim = (int64_t)ev.M + C1V_SLACK_ROWS - 1;
+            const char* src[IPA];
+#pragma unroll
+            for (int i = 0; i < IPA; ++i) {
+                const int row = 8 * i + prow;
+                int64_t r = (int64_t)p.a_off + m0 + row;
+                if (r > lim) r = lim;
+                src[i] = p.A + r * p.lda_b + ((ppos ^ ((row >> 1) & 7)) << 4);
+            }
+            auto issue = [&](int s) {
+                char* d = sA + (s & 1) * NTW_A_STAGE;
+                const int64_t ko = (int64_t)s * 128;
+#pragma unroll
+                for (int i = 0; i < IPA; ++i) glds16(src[i] + ko, d + i * 1024);
+            };
+            issue(0);
+            if (strips > 1) issue(1);
+            int tap = 0, s = 0;                            // tile t = (strip s, tap)
+            for (int t = 0; t < KT; ++t) {
+                // barrier t promises the window of tile t+1: strip 0 at t = 0, afterwards a new strip whenever tile t+1 is a tap 0
+                if (t == 0) { if (strips > 1) wait_vmcnt<IPA>(); else wait_vmcnt<0>(); }
+                else if (tap == taps - 1) wait_vmcnt<0>();
+                block_barrier();
+                // everybody is done with tile t-1: at the first tile of strip s >= 1 the stage of strip s-1 is free for s+1
+                if (tap == 0 && s >= 1 && s + 1 < strips) issue(s + 1);
+                if (++tap == taps) { tap = 0; ++s; }
+            }
+        } else {
+            // ---- weight tiles: rows n0 + [0, 128), K tile t = (strip t / taps, tap t % taps) at byte offset tap*k_strips*128 + strip*128
+            const char* src[IPW];
+#pragma unroll
+            for (int i = 0; i < IPW; ++i) {
+                const int row = 8 * i + prow;
+                int n = n0 + row;
+                if (n >= ev.N) n = ev.N - 1;
+                src[i] = p.W + (int64_t)n * p.ldw_b + ((ppos ^ ((row >> 1) & 7)) << 4);
+            }
+            int tap_i = 0;
+            int64_t ko = 0;
+            const int64_t tap_b = (int64_t)strips * 128;
+            auto issue = [&](int kt) {
+                char* d = sW + (kt % NTW_NSW) * NTW_W_STAGE;
+#pragma unroll
+                for (int i = 0; i < IPW; ++i) glds16(src[i] + ko, d + i * 1024);
+                if (++tap_i == taps) { tap_i = 0; ko += 128 - (int64_t)(taps - 1) * tap_b; } else ko += tap_b;
+            };
+#pragma unroll
+            for (int t = 0; t < NTW_NSW - 1; ++t)
+                if (t < KT) issue(t);
+            for (int t = 0; t < KT; ++t) {
+                // issued so far: tiles < min(KT, t + NSW - 1); tiles <= t+1 must have landed
+                if (t + 4 <= KT) wait_vmcnt<2 * IPW>(); else if (t + 3 == KT) wait_vmcnt<IPW>(); else wait_vmcnt<0>();
+                block_barrier();                           // everybody is done with tile t-1: its stage takes tile t+4
+                if (t + NTW_NSW - 1 < KT) issue(t + NTW_NSW - 1);
+            }
+        }
+        block_barrier();                                   // the two barriers of the epilogue below
+        block_barrier();
+        return;
+    }
+
+    f32x4_t acc[MI][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    // bias of this thread's epilogue channel group (see epilogue_rows): requested now, consumed after the K loop
+    float bias4[4] = {0.f, 0.f, 0.f, 0.f};
+    {
+        const int nbias = n0 + 4 * (tid % (BN / 4));
+        if (ev.bias && ev.bias_row_w > 0) {
+            const int tb = nbias / ev.reshape_w, cb = nbias - tb * ev.reshape_w;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                int t2 = tb, c2 = cb + k;
+                if (c2 >= ev.reshape_w) { c2 -= ev.reshape_w; ++t2; }
+                bias4[k] = (nbias + k < ev.N && c2 < ev.bias_row_w) ? ev.bias[t2 * ev.bias_row_w + c2] : 0.0f;
+            }
+        } else if (ev.bias) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) bias4[k] = nbias + k < ev.N ? ev.bias[nbias + k] : 0.0f;
+        }
+    }
+
+    // fragment addresses: A fragment i of tap j = window row 64 wave + 16 i + (lane & 15) + j, chunk kk*4 + (lane >> 4); the
+    // swizzle depends on the row through (row >> 1) & 7 only, which the + 16 i and + 64 wave steps leave alone, and the
+    // second half of the K tile (kk = 1) is the first one's address with bit 6 flipped
+    const int fr = lane & 15, fc = lane >> 4;
+    // (byte offsets from `smem`; every stage offset is a multiple of 128, so bit 6 belongs to the chunk index)
+    const int a_wave = wave * 64 * 128;
+    const int b_lane = NTW_NSA * NTW_A_STAGE + lds_off(fr, fc);
+    auto a_addr = [&](int s, int tap) -> int { return (s & 1) * NTW_A_STAGE + a_wave + lds_off(fr + tap, fc); };
+    auto b_addr = [&](int t) -> int { return (t % NTW_NSW) * NTW_W_STAGE + b_lane; };
+    auto ld = [&](int base, int frag, int kk) -> uint4 { return *(const uint4*)(smem + ((base ^ (kk * 64)) + frag * 16 * 128)); };
+
+    uint4 af[2][MI], bf[4];
+    NT_T(1);
+    block_barrier();                                       // barrier 0: tiles 0 and 1 are in LDS
+    NT_T(7);
+    {
+        const int a0 = a_addr(0, 0), b0 = b_addr(0);
+#pragma unroll
+        for (int i = 0; i < MI; ++i) af[0][i] = ld(a0, i, 0);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) bf[j] = ld(b0, j, 0);
+    }
+    int tap = 0, s = 0;
+    for (int t = 0; t < KT; ++t) {
+        const int a_cur = a_addr(s, tap), b_cur = b_addr(t);
+        int tapn = tap + 1, sn = s;
+        if (tapn == taps) { tapn = 0; ++sn; }
+        const bool more = t + 1 < KT;                      // wave-uniform
+        const int a_nxt = a_addr(sn, tapn), b_nxt = b_addr(t + 1);
+#pragma unroll
+        for (int g = 0; g < 2 * NJ; ++g) {
+            const int kk = g >> 3, j = g & 7;
+            // reads that run ahead: the weight fragment of group g+3 and, one per group, the activation fragments of the
+            // next half tile (groups 0-3: kk = 1 of this tile; groups 8-11: kk = 0 of the next tile, which barrier t has
+            // promised)
+            const int gn = g + 3;
+            if (gn < 2 * NJ) bf[gn & 3] = ld(b_cur, gn & 7, gn >> 3);
+            else if (more) bf[gn & 3] = ld(b_nxt, gn & 7, 0);
+            if (g < MI) af[1][g] = ld(a_cur, g, 1);
+            else if (g >= NJ && g < NJ + MI && more) af[0][g - NJ] = ld(a_nxt, g - NJ, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < MI; ++i) mma16<T>(acc[i][j], af[kk][i], bf[g & 3]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        tap = tapn; s = sn;
+        if (more) block_barrier();                         // barrier t+1
+    }
+
+    // ---- epilogue through LDS (see nt_body): the 256 x 128 tile parked as fp32, walked by rows
+    NT_T(2);
+    float* ct = (float*)smem;
+    block_barrier();                                       // every wave is done reading the last operand stages
+    NT_T(4);
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                ct[(wave * 64 + i * 16 + (lane >> 4) * 4 + r) * NTW_LDC + j * 16 + (lane & 15)] = acc[i][j][r];
+    block_barrier();
+    NT_T(5);
+    // (one row mode per instantiation, 4-wide vector epilogue only -- the host takes this variant for such launches only: with
+    // every mode in one kernel the epilogue was 26 k instructions of straight-line code and ~3 k SGPR spill moves, and with one
+    // workgroup per CU nothing overlaps it)
+    epi_seq_rows<BM, BN, MODE, 4>(ev, rd, ct, NTW_LDC, m0, n0, tid, bias4);
+#ifdef NT_STAMP
+    NT_T(6);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    NT_T(3);
+    if (tid == 0 && blockIdx.x < 8192) for (int i = 0; i < 8; ++i) nt_dbg[blockIdx.x * 16 + i] = stamp[i];
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------------
 // TN kernel (wgrad): 128x128 output tile, K loop over rows r; operands are read "down the columns":
 //   bf16: ds_read_b64_tr_b16 (hardware transpose), fragment element 4w+q <-> row 16w + 4g + q of a 32-row step
 //   fp32: ds_read_b32 straight from the row-major tile (v_mfma_f32_16x16x4_f32 wants one k per lane group)
 // Row pitch = 128*esize + pad (bf16 +32 B, fp32 +64 B) keeps both read patterns conflict-free.  A tile image is
 // BR rows = 18 KiB, filled by 18 one-KiB LDS-DMA requests of that operand's feeder wave (waves 4 / 5, see nt_body).
 // ------------------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------------------
+// wgrad epilogue: one 128 x 128 accumulator tile -> out[ii * si + jj * sj] through LDS.  Straight from the MFMA layout
+// every store instruction of the old epilogue wrote 4 x 16 scattered values (64 different 4-byte addresses when the
+// contiguous index of the slab was the one the accumulator holds in its REGISTERS -- the (k,1,F,C) layout of the transposed
+// convolutions); at C4, with 196 KB of slab per workgroup, that store tail was longer than the K loop.  The tile is parked
+// in LDS with the memory-contiguous index fastest and written out 256 consecutive bytes per wave instruction.
+// All 256 compute threads call it; `ct` = TN_CT_LD * 128 floats of LDS that nobody reads any more.
+// ------------------------------------------------------------------------------------------------------
+constexpr int TN_CT_LD = 132;
+__device__ __forceinline__ void tn_park_tile(const TnParams& p, float* ct, const f32x4_t (&acc)[4][4], int wi, int wj, int lane) {
+    if (p.sj == 1) {                                     // (wave-uniform) j contiguous in memory: ct[i][j]
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    ct[(wi * 64 + i * 16 + (lane >> 4) * 4 + r) * TN_CT_LD + wj * 64 + j * 16 + (lane & 15)] = acc[i][j][r];
+    } else {                                             // i contiguous: ct[j][i], the four registers of a fragment as one word
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                *(float4*)(ct + (wj * 64 + j * 16 + (lane & 15)) * TN_CT_LD + wi * 64 + i * 16 + (lane >> 4) * 4) =
+                    make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+    }
+}
+__device__ __forceinline__ void tn_write_tile(const TnParams& p, const float* ct, float* out, int i0, int j0, int tid) {
+    const bool jfast = p.sj == 1;
+    const int n_major = jfast ? p.I - i0 : p.J - j0, n_minor = jfast ? p.J - j0 : p.I - i0;     // valid extents of this tile
+    const int64_t s_major = jfast ? p.si : p.sj, s_minor = jfast ? p.sj : p.si;
+    float* o = out + (int64_t)(jfast ? i0 : j0) * s_major + (int64_t)(jfast ? j0 : i0) * s_minor;
+    const int minor = tid & 127, m0 = tid >> 7;
+    if (minor >= n_minor) return;
+#pragma unroll 8
+    for (int e = 0; e < 64; ++e) {
+        const int major = 2 * e + m0;
+        if (major < n_major) o[(int64_t)major * s_major + (int64_t)minor * s_minor] = ct[major * TN_CT_LD + minor];
+    }
+}
+
 template <typename T> struct TnCfg;
 template <> struct TnCfg<bf16_raw> { static constexpr int BR = 64, PITCH = 128 * 2 + 32; };
 template <> struct TnCfg<float>    { static constexpr int BR = 32, PITCH = 128 * 4 + 64; };
@@ -770,6 +1025,7 @@ __device__ __forceinline__ void tn_body(const TnParams& p, const int bx, const i
             block_barrier();
             if (kt + TN_NS - 1 < KT) issue(kt + TN_NS - 1);
         }
+        block_barrier(); block_barrier(); block_barrier();     // the barriers of the epilogue below
         return;
     }
 
@@ -840,20 +1096,12 @@ __device__ __forceinline__ void tn_body(const TnParams& p, const int bx, const i
     }
 
     const int tap_dst = p.flip ? (p.taps - 1 - tap) : tap;
-    float* out = p.out + (int64_t)split * p.slab_stride + (int64_t)tap_dst * p.tap_stride;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int ii = i0 + wi * 64 + i * 16 + (lane >> 4) * 4 + r;
-            if (ii >= p.I) continue;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int jj = j0 + wj * 64 + j * 16 + (lane & 15);
-                if (jj < p.J) out[(int64_t)ii * p.si + (int64_t)jj * p.sj] = acc[i][j][r];
-            }
-        }
-    }
+    float* ct = (float*)smem;
+    block_barrier();                                       // every wave is done reading the last operand stage
+    tn_park_tile(p, ct, acc, wi, wj, lane);
+    block_barrier();
+    tn_write_tile(p, ct, p.out + (int64_t)split * p.slab_stride + (int64_t)tap_dst * p.tap_stride, i0, j0, tid);
+    block_barrier();
     if (do_bias && (lane >> 4) == 0) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -864,8 +1112,215 @@ __device__ __forceinline__ void tn_body(const TnParams& p, const int bx, const i
 }
 
 
+// ------------------------------------------------------------------------------------------------------
+// TN kernel with the taps of a convolution FUSED into one workgroup (round 3).  The per-tap form above re-reads both
+// operands once per tap (and D once per 128 input channels on top): at C4's shapes the wgrad launches were bound by the
+// bytes a CU can take in from L2 (72 B/clk wanted at the MFMA rate, ~30 B/clk delivered), not by the MFMAs.  Here one
+// workgroup owns the same 128 x 128 (input channel x output channel) block of TG <= 3 consecutive taps: the A image
+// carries BR + TG - 1 rows, tap t reads it t rows further down, and the D fragments of a 32-row step feed the MFMAs of
+// every tap -- a third of the bytes in per MFMA and 16 instead of 24 fragment reads per 48 MFMAs.  The price is
+// TG x 64 accumulator registers per wave, i.e. one workgroup per CU, which a three-stage ring makes up for.
+// grid.z = ceil(taps / TG) * splits.
+// ------------------------------------------------------------------------------------------------------
+constexpr int TNF_A_IMG = 20 * 1024;                // BR + 2 rows of PITCH bytes, rounded up to whole 1 KiB requests
+constexpr int TNF_STAGE = TNF_A_IMG + TN_TILE;
+constexpr int TNF_NS = 3;
+constexpr int TNF_LDS = TNF_NS * TNF_STAGE;
+
+template <typename T, int TG>
+__device__ __forceinline__ void tn_taps_body(const TnParams& p, const int bx, const int by, const int bz) {
+    using Cfg = TnCfg<T>;
+    constexpr int BR = Cfg::BR, PITCH = Cfg::PITCH;
+    constexpr int ES = sizeof(T);
+    constexpr int CPR = PITCH / 16, DCH = 128 * ES / 16;
+    constexpr int NPA = TNF_A_IMG / 1024, NPD = BR * PITCH / 1024;
+    constexpr int AROWS = BR + TG - 1;
+    static_assert(TG >= 1 && TG <= 3 && AROWS * PITCH <= TNF_A_IMG && NPD * 1024 == BR * PITCH, "tile images");
+    static_assert((TNF_NS - 2) * NPA <= 63, "vmcnt is a 6-bit counter");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wi = wave >> 1, wj = wave & 1;
+    const int i0 = bx * 128, j0 = by * 128;
+    const int tgi = bz / p.splits, split = bz - tgi * p.splits;
+    const int tap0 = tgi * TG;
+    // (taps is a multiple of TG: host check)
+    const int64_t rb = p.r_begin + (int64_t)split * p.rows_per_split;
+    int64_t re = rb + p.rows_per_split;
+    if (re > p.r_end) re = p.r_end;
+    const int64_t nrows = re > rb ? re - rb : 0;
+    const int KT = (int)((nrows + BR - 1) / BR);
+
+    const char* abase = p.A + (rb + p.a_shift0 + tap0) * p.lda_b + (int64_t)i0 * ES;
+    const char* dbase = p.D + rb * p.ldd_b + (int64_t)j0 * ES;
+
+    if (wave >= 4) {
+        // ---- feeder (wave 4: A image, wave 5: D image); lanes that land in the row padding or behind the image's last
+        // row read the tile's first chunk
+        const bool feed_a = wave == 4;
+        const int64_t ld_b = feed_a ? p.lda_b : p.ldd_b;
+        const int col0_b = (feed_a ? i0 : j0) * ES, cols_b = (feed_a ? p.Ia : p.Ja) * ES;
+        const int rows_img = feed_a ? AROWS : BR;
+        int64_t off[NPA];
+#pragma unroll
+        for (int i = 0; i < NPA; ++i) {
+            const int Lc = i * 64 + lane;
+            int row = Lc / CPR;
+            int pos = Lc - row * CPR;
+            if (pos >= DCH || col0_b + pos * 16 >= cols_b) pos = 0;
+            if (row >= rows_img) { row = 0; pos = 0; }
+            off[i] = (int64_t)row * ld_b + pos * 16;
+        }
+        const char* base = feed_a ? abase : dbase;
+        const int dst0 = feed_a ? 0 : TNF_A_IMG;
+        auto issue = [&](int kt) {
+            char* d = smem + (kt % TNF_NS) * TNF_STAGE + dst0;
+            const char* t = base + (int64_t)kt * BR * ld_b;
+#if defined(TN_ABLATE) && (TN_ABLATE & 1)
+            if (kt < 0)                                    // diagnostic: no operand requests at all (compute side alone)
+#endif
+            if (feed_a) {
+#pragma unroll
+                for (int i = 0; i < NPA; ++i) glds16(t + off[i], d + i * 1024);
+            } else {
+#pragma unroll
+                for (int i = 0; i < NPD; ++i) glds16(t + off[i], d + i * 1024);
+            }
+        };
+#pragma unroll
+        for (int s = 0; s < TNF_NS - 1; ++s)
+            if (s < KT) issue(s);
+        for (int kt = 0; kt < KT; ++kt) {
+            // tiles requested so far: min(KT, kt + NS - 1); all but the NS-2 youngest must have landed
+            if (kt + TNF_NS - 2 < KT) { if (feed_a) wait_vmcnt<(TNF_NS - 2) * NPA>(); else wait_vmcnt<(TNF_NS - 2) * NPD>(); }
+            else wait_vmcnt<0>();
+            block_barrier();
+            if (kt + TNF_NS - 1 < KT) issue(kt + TNF_NS - 1);
+        }
+#pragma unroll
+        for (int b = 0; b < 1 + 2 * TG; ++b) block_barrier();     // the barriers of the epilogue below
+        return;
+    }
+
+    f32x4_t acc[TG][4][4];
+#pragma unroll
+    for (int t = 0; t < TG; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[t][i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    f32x4_t accb[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) accb[j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    const bool do_bias = p.bias_out != nullptr && bx == 0 && tgi == 0 && wi == 0;     // wave-uniform
+
+    for (int kt = 0; kt < KT; ++kt) {
+        block_barrier();
+        const char* sa = smem + (kt % TNF_NS) * TNF_STAGE;
+        const char* sd = sa + TNF_A_IMG;
+#if defined(TN_ABLATE) && (TN_ABLATE & 2)
+        if (kt >= 0) continue;                             // diagnostic: no fragment reads, no MFMAs (feed side alone)
+#endif
+        if constexpr (sizeof(T) == 2) {
+            // One wave per SIMD: nothing but this wave's own instruction stream hides the LDS latency, so the fragment reads run
+            // one GROUP (two A fragments = 8 MFMAs = 128 cycles) ahead of the MFMAs that use them; sched_barrier(0) pins
+            // "reads of group g+1, then MFMAs of group g" (left alone, the compiler put every read in front of its first use:
+            // one LDS round trip per four MFMAs, 3.6 x the MFMA time at C4).  The D fragments of the next 32-row step are
+            // requested right behind the last MFMAs of this one and arrive while those drain.
+            const int g = lane >> 4, q = (lane & 15) >> 2, pq = lane & 3;
+            const char* arow = sa + (4 * g + q) * PITCH + (wi * 64 + 4 * pq) * 2;
+            const char* drow = sd + (4 * g + q) * PITCH + (wj * 64 + 4 * pq) * 2;
+            constexpr int KS = BR / 32, NG = 2 * TG;
+            auto ldf = [&](const char* p0) -> uint4 {
+                s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(C1V_LDS_PTR(s16x4_t, p0));
+                s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(C1V_LDS_PTR(s16x4_t, p0 + 16 * PITCH));
+                return make_uint4(__builtin_bit_cast(uint2, lo).x, __builtin_bit_cast(uint2, lo).y,
+                                  __builtin_bit_cast(uint2, hi).x, __builtin_bit_cast(uint2, hi).y);
+            };
+            uint4 df[4], af[2][2];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) df[j] = ldf(drow + j * 32);
+#pragma unroll
+            for (int e = 0; e < 2; ++e) af[0][e] = ldf(arow + e * 32);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+                for (int gi = 0; gi < NG; ++gi) {
+                    const int t = gi >> 1, i0 = (gi & 1) * 2;
+                    if (gi + 1 < NG) {
+                        const int tn = (gi + 1) >> 1, in0 = ((gi + 1) & 1) * 2;
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) af[(gi + 1) & 1][e] = ldf(arow + (ks * 32 + tn) * PITCH + (in0 + e) * 32);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int e = 0; e < 2; ++e)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) mma16<bf16_raw>(acc[t][i0 + e][j], af[gi & 1][e], df[j]);
+                    if (gi == 0 && do_bias) {
+                        const uint4 ones = make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) mma16<bf16_raw>(accb[j], ones, df[j]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (gi + 1 == NG && ks + 1 < KS) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) df[j] = ldf(drow + (ks + 1) * 32 * PITCH + j * 32);
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) af[0][e] = ldf(arow + (ks + 1) * 32 * PITCH + e * 32);
+                    }
+                }
+            }
+        } else {
+            const char* arow = sa + (lane >> 4) * PITCH + (wi * 64 + (lane & 15)) * 4;
+            const char* drow = sd + (lane >> 4) * PITCH + (wj * 64 + (lane & 15)) * 4;
+#pragma unroll 2
+            for (int ks = 0; ks < BR / 4; ++ks) {
+                float df[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) df[j] = *(const float*)(drow + ks * 4 * PITCH + j * 64);
+#pragma unroll
+                for (int t = 0; t < TG; ++t) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float af = *(const float*)(arow + (ks * 4 + t) * PITCH + i * 64);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, df[j], acc[t][i][j], 0, 0, 0);
+                    }
+                }
+                if (do_bias) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) accb[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, df[j], accb[j], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    float* ct = (float*)smem;
+    block_barrier();                                       // every wave is done reading the last operand stage
+#pragma unroll
+    for (int t = 0; t < TG; ++t) {
+        const int tap = tap0 + t;
+        const int tap_dst = p.flip ? (p.taps - 1 - tap) : tap;
+        tn_park_tile(p, ct, acc[t], wi, wj, lane);
+        block_barrier();
+        tn_write_tile(p, ct, p.out + (int64_t)split * p.slab_stride + (int64_t)tap_dst * p.tap_stride, i0, j0, tid);
+        block_barrier();
+    }
+    if (do_bias && (lane >> 4) == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int jj = j0 + wj * 64 + j * 16 + (lane & 15);
+            if (jj < p.J) p.bias_out[(int64_t)split * p.bias_slab_stride + jj] = accb[j][0];
+        }
+    }
+}
+
 // LDS needs and tile choice, shared by the launchers of c1v_gemm.hip and c1v_gemm_pair.hip
 constexpr int TN_LDS = TN_NS * 2 * TN_TILE;
+static_assert(TN_LDS >= TN_CT_LD * 128 * 4 && TNF_LDS >= TN_CT_LD * 128 * 4, "the parked wgrad tile must fit the operand ring");
 enum NtVariant { NT_128 = 0, NT_128L = 1, NT_64 = 2 };
 // LDS of an NT workgroup: the operand ring, reused by the epilogue for the parked fp32 tile (BM x (BN + 4))
 template <int BM, int BN, int NS> constexpr int nt_lds() {

@@ -677,10 +677,35 @@ class VAEEngine:
             by_fill = (wgrad_wgs_alone if alone else wgrad_wgs) // max(1, tile_taps)      # (rounded down)
             return int(max(1, min(by_rows, by_fill, wgrad_max)))
 
+        # Taps fused into one workgroup (c1v_wgrad_args::tap_group; round 3): both operands come into the CU once for all
+        # taps, which is what bounded the per-tap form at C4.  Needs 128 x 128 tiles x row splits alone to fill the chip
+        # (one 249-register workgroup per CU); such a wgrad is a launch of its own, not paired with the layer's dgrad.
+        # OPT-IN (C1V_WGRAD_FUSE=1, or =auto: by size).  Measured at C4 (profiles/r03_c4_wgrad_fused.txt): alone a fused wgrad
+        # takes 54-57 us where the per-tap form takes 79-89, and reads each operand from HBM once instead of 2-4 times; but
+        # the per-tap form shares its grid with the layer's dgrad tiles (c1v_bwd_pair, two workgroups per CU) and the PAIR
+        # finishes in 96-140 us where fused wgrad + dgrad take 106-155 one after the other.
+        fuse_env = os.environ.get('C1V_WGRAD_FUSE', '')
+        fuse_wgs = int(os.environ.get('C1V_WGRAD_WGS_FUSED', '256'))
+        self.wgrad_fused: Dict[str, int] = {}
+
         def conv_wgrad(X: Buf, dO: Buf, wname: str, bname: str, C_in: int, F: int, flip: int, tap_stride, si, sj, frozen=False,
                        alone=False):
             rows = B * X.pitch
-            sp = row_splits(rows, k * (-(-C_in // 128)) * (-(-F // 128)), alone)
+            tiles = (-(-C_in // 128)) * (-(-F // 128))
+            tg = 0
+            if k > 1:
+                tgc = 3 if k % 3 == 0 else (2 if k % 2 == 0 else 0)           # (the group size must divide the taps)
+                groups = k // tgc if tgc else 0
+                if tgc and (fuse_env == '1' or (fuse_env == 'auto' and tiles * groups * (rows // wgrad_rows) >= 256)):
+                    tg = tgc
+            if tg:
+                # the workgroups of one row split go to one XCD (32 CUs, one workgroup each): whole splits per XCD
+                per_split = tiles * (k // tg)
+                sp = 8 * max(1, (fuse_wgs // 8) // per_split)
+                sp = int(max(1, min(rows // wgrad_rows, sp, wgrad_max)))
+            else:
+                sp = row_splits(rows, k * tiles, alone)
+            self.wgrad_fused[wname] = tg
             wt = slab(wname, sp, frozen)
             bt = slab(bname, sp, frozen)
             count = int(np.prod(self.seg_shapes[wname]))
@@ -688,7 +713,7 @@ class VAEEngine:
                 return None
             return ('c1v_conv1d_wgrad', L.WgradArgs(X.t.data_ptr(), X.cp, C_in, dO.t.data_ptr(), dO.cp, F,
                                                     self.code, k - 1, rows, -(k - 1), k, flip, tap_stride, si, sj,
-                                                    wt.data_ptr(), count, sp, bt.data_ptr(), F))
+                                                    wt.data_ptr(), count, sp, bt.data_ptr(), F, tg))
 
         def dense_wgrad(a_ptr, lda, I, d_ptr, ldd, J, wname, bname, frozen=False):
             wt = slab(wname, 1, frozen)
@@ -708,7 +733,10 @@ class VAEEngine:
             """dgrad / wgrad: (entry point, args) or None; before / after: extra ops (side / main in the two-stream form)."""
             main = ([op(*dgrad)] if dgrad else []) + list(after)
             side = list(before) + ([op(*wgrad)] if wgrad else [])
-            if dgrad and wgrad:
+            if dgrad and wgrad and getattr(wgrad[1], 'tap_group', 0) >= 2:
+                # a fused-tap wgrad fills the chip by itself and runs one 232-register workgroup per CU: own launch
+                fused = side + main
+            elif dgrad and wgrad:
                 is_dense = isinstance(dgrad[1], L.DenseArgs)
                 self._keep += [dgrad[1], wgrad[1]]
                 pa = L.BwdPairArgs(None if is_dense else C.pointer(dgrad[1]), C.pointer(dgrad[1]) if is_dense else None,

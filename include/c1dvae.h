@@ -148,6 +148,10 @@ typedef struct c1v_wgrad_args {
     int32_t     splits;
     float*      bias_out;        /* optional: bias_out[s*bias_slab_stride + j] = sum_{r in split s} D[r*ldd + j] (bias gradient) */
     int64_t     bias_slab_stride;
+    int32_t     tap_group;       /* 0 / 1: one workgroup per (tile, tap, split).  2 / 3: that many consecutive taps share a
+                                    workgroup, which fetches both operands once for all of them (a third of the bytes into the
+                                    CU per MFMA, 192 accumulator registers per wave): for launches whose tiles x splits fill
+                                    the chip without the tap dimension; must divide `taps`.  Results are bit-identical either way. */
 } c1v_wgrad_args;
 int c1v_wgrad(const c1v_wgrad_args*, void* stream);
 int c1v_conv1d_wgrad(const c1v_wgrad_args*, void* stream);

@@ -195,6 +195,55 @@ def test_paired_backward_launch_is_bit_identical(name, dtype, monkeypatch):
         np.testing.assert_array_equal(got['1'][0][k_], v, err_msg=k_)
 
 
+@pytest.mark.parametrize('name', ['deep3', 'k4', 'k2', 'mid', 'big128'])
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_fused_tap_wgrad_is_bit_identical(name, dtype, monkeypatch):
+    """c1v_wgrad_args::tap_group (the taps of a convolution's weight gradient in ONE workgroup: both operands fetched once
+    for all taps; taken by itself for large batches, forced here) against one workgroup per tap: every output element sums
+    the same products in the same order, so the gradients must agree to the bit (k = 2, 3, 4; k = 4 runs two groups of
+    two taps)."""
+    c = CASES[name]
+    og, params, Wv, x, ids, eps, mask_e, mask_d = make_case(c)
+    monkeypatch.setenv('C1V_WGRAD_MAX_SPLITS', '8')          # the same row splits both ways
+    got = {}
+    for mode in ('1', '0'):
+        monkeypatch.setenv('C1V_WGRAD_FUSE', mode)
+        eng = build_engine(c, og, params, Wv, dtype)
+        assert all((tg >= 2) == (mode == '1') for tg in eng.wgrad_fused.values()), eng.wgrad_fused
+        load_fixed(eng, x, ids, eps, mask_e, mask_d)
+        eng._run(eng.train_ops(False))
+        torch.cuda.synchronize()
+        got[mode] = (eng.get_grads(), eng.loss())
+    assert got['1'][1] == got['0'][1]
+    for k_, v in got['0'][0].items():
+        np.testing.assert_array_equal(got['1'][0][k_], v, err_msg=k_)
+
+
+@pytest.mark.parametrize('name', ['deep3', 'k4', 'k2', 'mid', 'wide', 'big128'])
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_wide_window_nt_variant_is_bit_identical(name, dtype, monkeypatch):
+    """The wide NT variant (256 x 128 tiles over the flat buffer rows, the activation window of a channel strip fetched
+    once for all taps; taken by itself for the large convolutions of C4, forced here with C1V_NTW=1 onto every convolution
+    whose channel pitch is whole 128-byte strips) against the 64 x 64 / 128 x 128 kernels: the same products summed in
+    the same order, so activations, loss and gradients must agree to the bit -- all epilogue modes (pool, upsample + crop,
+    pair sum, un-pool), k = 2, 3, 4, ragged tiles, samples that straddle tiles."""
+    c = CASES[name]
+    og, params, Wv, x, ids, eps, mask_e, mask_d = make_case(c)
+    got = {}
+    for mode in ('1', '0'):
+        monkeypatch.setenv('C1V_NTW', mode)
+        eng = build_engine(c, og, params, Wv, dtype)
+        load_fixed(eng, x, ids, eps, mask_e, mask_d)
+        eng._run(eng.train_ops(False))
+        torch.cuda.synchronize()
+        got[mode] = (eng.get_grads(), eng.loss(), eng.y_pred().cpu().numpy(), eng.mlv.cpu().numpy())
+    assert got['1'][1] == got['0'][1]
+    np.testing.assert_array_equal(got['1'][2], got['0'][2])
+    np.testing.assert_array_equal(got['1'][3], got['0'][3])
+    for k_, v in got['0'][0].items():
+        np.testing.assert_array_equal(got['1'][0][k_], v, err_msg=k_)
+
+
 @pytest.mark.parametrize('dtype', ['f32', 'bf16'])
 def test_step_prologue_and_live_rows_are_bit_identical(dtype, monkeypatch):
     """One-launch step prologue (rng + input pack + live-row table) and the compacted loss rows against the separate
