@@ -485,17 +485,18 @@ class VAEEngine:
         def reduce_():
             L.check(f_red(ref, 1, st['partial'].data_ptr(), L.BN_BLOCKS, st['sums_b'].data_ptr(), 1.0, self._stream()), 'c1v_bn_reduce')
 
+        def share():
+            # gamma / beta gradients: this rank's LOCAL sums go into the flat gradient (a device-to-device copy, taken before
+            # the collective below), whose all-reduce over the ranks makes them the sums of the global batch
+            st['slab'].copy_(st['sums_b'], non_blocking=True)
+
         def sync():
             self._bn_sync_sums(st['sums_b'])
         sync.bn_sync = st['sums_b']
 
-        def share():
-            # the flat gradient is summed over the ranks once more later: hand it this rank's share of the global sums
-            torch.mul(st['sums_b'], 1.0 / self.world, out=st['slab'])
-
         def apply():
             L.check(f_app(ref, self._stream()), 'c1v_bn_apply_bwd')
-        return [reduce_, sync, share, apply]
+        return [reduce_, share, sync, apply]
 
     def _build_ops(self):
         g, k, B = self.g, self.g.kernel_size, self.B

@@ -31,7 +31,7 @@ from sklearn.utils.validation import check_is_fitted
 from . import embeddings as E
 from .geometry import Geometry, init_keras_weights
 from .tokenizer import BaseTokenizer, DefaultTokenizer
-from .training import run_epochs
+from .training import run_epochs, run_epochs_dp
 
 EPSILON = 1e-7                    # keras.backend.epsilon()
 FITTED_ATTRIBUTES = ['input_text_size_', 'output_text_size_', 'input_vector_size_', 'output_vector_size_',
@@ -75,17 +75,24 @@ class _VAERuntime:
             self._engine = self._make(None, False)
         return self._engine
 
-    def training_engine(self, vocab_vectors: np.ndarray, frozen_encoder: bool = False):
-        """A fresh engine that also owns the vocabulary matrix W of the loss and the optimizer state."""
+    def training_engine(self, vocab_vectors: np.ndarray, frozen_encoder: bool = False, dp=None):
+        """A fresh engine that also owns the vocabulary matrix W of the loss and the optimizer state.  dp (dist.DataParallel,
+        world > 1): this rank's engine of a data-parallel fit -- `batch / world` samples per step, gradients all-reduced."""
         w = self.weights()
         self._engine = None
-        self._engine = self._make(vocab_vectors, frozen_encoder, w)
+        if dp is not None and dp.world > 1:
+            _, local = dp.batch_slice(self.batch)
+            self._engine = self._make(vocab_vectors, frozen_encoder, w, batch=local, world=dp.world, rank=dp.rank)
+            self._engine_is_rank_slice = True
+        else:
+            self._engine = self._make(vocab_vectors, frozen_encoder, w)
         return self._engine
 
-    def _make(self, vocab_vectors, frozen_encoder, weights=None):
+    def _make(self, vocab_vectors, frozen_encoder, weights=None, batch=None, world=1, rank=0):
         from .engine import VAEEngine
-        return VAEEngine(self.geom, self.batch, vocab_vectors, dtype=self.dtype, device=self.device, seed=self.seed,
-                         frozen_encoder=frozen_encoder, weights=weights if weights is not None else self._weights)
+        return VAEEngine(self.geom, self.batch if batch is None else batch, vocab_vectors, dtype=self.dtype,
+                         device=self.device, seed=self.seed, world_size=world, rank=rank, frozen_encoder=frozen_encoder,
+                         weights=weights if weights is not None else self._weights)
 
     def weights(self) -> Dict[str, np.ndarray]:
         if self._engine is not None:
@@ -420,17 +427,28 @@ class Conv1dTextVAE(BaseEstimator, TransformerMixin, ClassifierMixin):
             else:
                 self.input_text_size_ = self.input_text_size
         self._release_models()
-        seed = int(np.random.randint(0, 2 ** 31 - 1))
+        # Data parallel under torchrun (WORLD_SIZE > 1: one process per GPU, RCCL): `batch_size` stays the GLOBAL batch of one
+        # optimizer step and every rank computes its contiguous share of it (dist.DataParallel, training.run_epochs_dp).
+        # Rank 0's seed initialises the weights, the shuffles and the generator on every rank.
+        from .dist import DataParallel
+        dp = DataParallel.from_env()
+        if dp.world > 1:
+            dp.batch_slice(self.batch_size)                              # (raises if the batch does not divide)
+            self.device = dp.device_str
+        seed = dp.broadcast_int(int(np.random.randint(0, 2 ** 31 - 1)))
+        chatty = bool(self.verbose) and dp.rank == 0
         runtime, generator = self._create_model(self.input_vector_size_, self.output_vector_size_, seed,
                                                 encoder_weights=encoder_weights)
-        engine = runtime.training_engine(output_word_vectors, frozen_encoder=bool(self.warm_start))
-        if self.verbose:
+        engine = runtime.training_engine(output_word_vectors, frozen_encoder=bool(self.warm_start), dp=dp)
+        if chatty:
             self._print_summary(runtime.geom, generator)
         self._fit_vae(engine, input_texts, target_texts, n_train, input_vocabulary, input_word_vectors,
-                      output_vocabulary, output_word_vectors)
+                      output_vocabulary, output_word_vectors, dp=dp, seed=seed)
         self._fit_seq2seq(runtime, engine, generator, input_texts, target_texts_by_characters, n_train, input_vocabulary,
-                          input_word_vectors)
+                          input_word_vectors, dp=dp, seed=seed)
         runtime.weights()
+        if dp.world > 1:
+            runtime.release(keep_weights=True)          # inference runs whole batches: a full-batch engine is built on demand
         self._vae_runtime = runtime
         self._generator = generator
         self.vae_encoder_ = VAEEncoderModel(runtime)
@@ -440,8 +458,12 @@ class Conv1dTextVAE(BaseEstimator, TransformerMixin, ClassifierMixin):
         return self
 
     def _fit_vae(self, engine, input_texts, target_texts, n_train, input_vocabulary, input_word_vectors,
-                 output_vocabulary, output_word_vectors):
+                 output_vocabulary, output_word_vectors, dp=None, seed=None):
         import torch
+        from .dist import DataParallel
+        dp = dp if dp is not None else DataParallel()
+        chatty = bool(self.verbose) and dp.rank == 0
+        all_reduce = dp.all_reduce_async if dp.world > 1 else None
         B = self.batch_size
         mk = lambda a, b: SequenceForVAE(
             input_texts=input_texts[a:b], target_texts=target_texts[a:b], tokenizer=self.tokenizer, batch_size=B,
@@ -456,45 +478,56 @@ class Conv1dTextVAE(BaseEstimator, TransformerMixin, ClassifierMixin):
         ev_in, ev_out = (torch.from_numpy(a).to(dev) for a in eval_set.all_ids())
         acc = torch.zeros(4, dtype=torch.float64, device=dev)            # train loss sum, n, val loss sum, n
 
-        def train_batch(i):
-            engine.in_ids.copy_(tr_in[i * B:(i + 1) * B])
-            engine.ids_in.copy_(tr_out[i * B:(i + 1) * B])
-            engine.train_step(from_ids=True)
+        # (first, count): this rank's samples of a global batch; the engine's loss already carries 1/B_global, so the
+        # per-rank losses ADD UP to the batch loss (run_epochs_dp sums them over the ranks once per epoch)
+        def train_slice(first, count):
+            engine.in_ids.copy_(tr_in[first:first + count])
+            engine.ids_in.copy_(tr_out[first:first + count])
+            engine.train_step(from_ids=True, all_reduce=all_reduce)
             acc[0] += engine.loss_out[0]
             acc[1] += 1
 
-        def eval_batch(i):
-            engine.in_ids.copy_(ev_in[i * B:(i + 1) * B])
-            engine.ids_in.copy_(ev_out[i * B:(i + 1) * B])
+        def eval_slice(first, count):
+            engine.in_ids.copy_(ev_in[first:first + count])
+            engine.ids_in.copy_(ev_out[first:first + count])
             engine.eval_step(from_ids=True)
             acc[2] += engine.loss_out[0]
             acc[3] += 1
 
-        def epoch_losses():
-            a = acc.cpu().numpy()
+        def local_sums():
+            a = acc.cpu().numpy().copy()
             acc.zero_()
-            return float(a[0] / max(a[1], 1.0)), float(a[2] / max(a[3], 1.0))
+            return a
+
+        # ModelCheckpoint(save_weights_only=True) saves every weight of the model (:312-316, :331-332): the trainable
+        # parameters AND the moving averages of the BatchNormalization layers
+        bn_state = [st[k] for st in engine.bn.values() for k in ('moving_mean', 'moving_var')]
 
         def snapshot():
-            return [t.clone() for t in (engine.params,)]
+            return [t.clone() for t in [engine.params] + bn_state]
 
         def restore(w):
-            engine.params.copy_(w[0])
+            for t, v in zip([engine.params] + bn_state, w):
+                t.copy_(v)
             engine._pack_all()
 
-        if self.verbose:
+        if chatty:
             print('')
             print('----------------------------------------')
             print('VAE training...')
             print('----------------------------------------')
             print('')
-        self.vae_history_ = run_epochs(len(train_set), len(eval_set), self.max_epochs, train_batch, eval_batch,
-                                       epoch_losses, engine.get_lr, engine.set_lr, snapshot, restore,
-                                       verbose=self.verbose, what='VAE')
+        self.vae_history_ = run_epochs_dp(dp, B, len(train_set), len(eval_set), self.max_epochs, train_slice, eval_slice,
+                                          local_sums, engine.get_lr, engine.set_lr, snapshot, restore,
+                                          verbose=self.verbose, seed=seed, what='VAE')
 
     def _fit_seq2seq(self, runtime, engine, generator, input_texts, target_texts_by_characters, n_train, input_vocabulary,
-                     input_word_vectors):
+                     input_word_vectors, dp=None, seed=None):
         import torch
+        from .dist import DataParallel
+        dp = dp if dp is not None else DataParallel()
+        chatty = bool(self.verbose) and dp.rank == 0
+        first, count = dp.batch_slice(self.batch_size)
         B = self.batch_size
         vae = FullVAEModel(runtime)
         mk = lambda a, b: SequenceForSeq2Seq(
@@ -513,10 +546,13 @@ class Conv1dTextVAE(BaseEstimator, TransformerMixin, ClassifierMixin):
             oh = torch.nn.functional.one_hot(ids.clamp(min=0).long(), n_chars).to(torch.float32)
             return oh * (ids >= 0).unsqueeze(-1).to(torch.float32)
 
+        # Data parallel: every rank reconstructs ITS samples of the batch with the VAE (the sampling noise is keyed by the
+        # global sample index), the word vectors are all-gathered, and the small recurrent generator trains replicated on
+        # the whole batch (same seed, same inputs => identical weights on every rank, no gradient exchange).
         def batch(data, i):
-            engine.in_ids.copy_(data[0][i * B:(i + 1) * B])
+            engine.in_ids.copy_(data[0][i * B + first:i * B + first + count])
             words = engine.sample_reconstruct(from_ids=True, postprocess=True)       # FullVAE.predict_on_batch + postprocess
-            words = torch.nan_to_num(words.clone(), nan=0.0, posinf=0.0, neginf=0.0)
+            words = dp.all_gather_rows(torch.nan_to_num(words.clone(), nan=0.0, posinf=0.0, neginf=0.0))
             return words, onehot(data[1][i * B:(i + 1) * B]), onehot(data[2][i * B:(i + 1) * B])
 
         def train_batch(i):
@@ -538,15 +574,16 @@ class Conv1dTextVAE(BaseEstimator, TransformerMixin, ClassifierMixin):
         def set_lr(v):
             generator.lr = float(v)
 
-        if self.verbose:
+        if chatty:
             print('')
             print('----------------------------------------')
             print('Seq2Seq training...')
             print('----------------------------------------')
             print('')
+        shuffle = np.random.RandomState(None if seed is None else (int(seed) + 2) % (2 ** 31 - 1)) if dp.world > 1 else None
         self.seq2seq_history_ = run_epochs(len(train_set), len(eval_set), self.max_epochs, train_batch, eval_batch,
                                            epoch_losses, get_lr, set_lr, generator.get_weights, generator.set_weights,
-                                           verbose=self.verbose, what='Seq2Seq')
+                                           verbose=chatty, rng=shuffle, what='Seq2Seq')
 
     # ---- inference ---------------------------------------------------------------------------------------
     def _special_symbols(self, none_if_empty: bool = False):

@@ -109,3 +109,34 @@ def run_epochs(n_train_batches: int, n_eval_batches: int, max_epochs: int, train
     if best.weights is not None:
         restore(best.weights)
     return history
+
+
+def run_epochs_dp(dp, global_batch: int, n_train_batches: int, n_eval_batches: int, max_epochs: int,
+                  train_slice: Callable[[int, int], None], eval_slice: Callable[[int, int], None],
+                  local_sums: Callable[[], np.ndarray], get_lr, set_lr, snapshot, restore, verbose=False,
+                  seed: Optional[int] = None, what: str = 'VAE'):
+    """`run_epochs` for `dp.world` data-parallel ranks (dist.DataParallel; world 1 = the plain loop).
+
+    `global_batch` samples make one optimizer step, as in the reference (:323-330); rank r computes samples
+    [first, first + count) = `dp.batch_slice(global_batch)` of every batch: `train_slice(first_sample, count)` /
+    `eval_slice(...)` receive ABSOLUTE sample offsets into the training / evaluation set.  `local_sums()` returns this
+    rank's (train loss sum, train batches, val loss sum, val batches) of the epoch and clears them; every loss term of a
+    rank already carries 1/B_global, so the SUM over the ranks is the full-batch loss.  The sums are all-reduced once per
+    epoch, hence every rank sees the same `val_loss` and takes the same EarlyStopping / ReduceLROnPlateau / best-weights
+    decision (:308-316); the batch order of an epoch comes from one seed broadcast by rank 0; only rank 0 prints."""
+    first, count = dp.batch_slice(global_batch)
+    shared_seed = dp.broadcast_int(int(np.random.randint(0, 2 ** 31 - 1)) if seed is None else int(seed))
+    rng = np.random.RandomState(shared_seed)
+
+    def train_batch(i):
+        train_slice(i * global_batch + first, count)
+
+    def eval_batch(i):
+        eval_slice(i * global_batch + first, count)
+
+    def epoch_losses():
+        a = dp.sum_over_ranks(local_sums())
+        return float(a[0] / max(a[1] / dp.world, 1.0)), float(a[2] / max(a[3] / dp.world, 1.0))
+
+    return run_epochs(n_train_batches, n_eval_batches, max_epochs, train_batch, eval_batch, epoch_losses, get_lr, set_lr,
+                      snapshot, restore, verbose=bool(verbose) and dp.rank == 0, rng=rng, what=what)

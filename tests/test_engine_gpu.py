@@ -491,3 +491,103 @@ def test_two_rank_bucketed_step_equals_single_rank_step():
         e.train_step(use_graph=True, fixed_rng=True, all_reduce=fake_all_reduce)
     torch.cuda.synchronize()
     assert calls[:3] == [hi - lo for _, _, (lo, hi) in e.dp_buckets] and np.isfinite(e.loss())
+
+
+def test_two_rank_fit_epochs_equal_the_single_rank_fit():
+    """The data-parallel fit loop of the estimator (training.run_epochs_dp, as Conv1dTextVAE._fit_vae drives it) with two
+    ranks emulated on one GPU: two half-batch engines (rank 0 / 1 of world 2) stepped through the bucketed sequence with
+    the all-reduce done by hand, device RNG on (draws are keyed by the GLOBAL sample index), against ONE engine running
+    whole batches through the same loop.  Two epochs of three shuffled batches + one evaluation batch: the same epoch
+    losses and the same weights (fp32; only the summation order of the gradient differs)."""
+    from conv1d_text_vae_amd import synthetic
+    from conv1d_text_vae_amd.dist import DataParallel
+    from conv1d_text_vae_amd.training import run_epochs_dp
+    engine, geometry = _engine_mod()
+    c = dict(CASES['mid'])
+    B, n_tr, n_ev = c['B'], 3, 1
+    og, params, Wv, _, _, _, _, _ = make_case(c, seed=4)
+    V = c['E'] + 2
+    g = geometry.Geometry(c['T_in'], c['T_out'], V, V, c['n_filters'], c['k'], c['D'])
+    _, ids, in_ids = synthetic.synthetic_batch(Wv, Wv.shape[0], B * (n_tr + n_ev), c['T_in'], c['T_out'], seed=21, with_input_ids=True)
+    tr_in, tr_out = torch.from_numpy(in_ids[:B * n_tr]).cuda(), torch.from_numpy(ids[:B * n_tr]).cuda()
+    ev_in, ev_out = torch.from_numpy(in_ids[B * n_tr:]).cuda(), torch.from_numpy(ids[B * n_tr:]).cuda()
+
+    def fit(engines, dp):
+        """engines: the engine of every emulated rank (one entry = the plain fit)."""
+        for e in engines:
+            e.set_input_table(Wv)
+        acc = torch.zeros(4, dtype=torch.float64, device='cuda')
+        n = len(engines)
+
+        def load(e, src_in, src_out, first, count):
+            e.in_ids.copy_(src_in[first:first + count])
+            e.ids_in.copy_(src_out[first:first + count])
+
+        def train_slice(first, count):
+            for r, e in enumerate(engines):
+                load(e, tr_in, tr_out, first + r * count, count)
+            if n == 1:
+                engines[0].train_step(use_graph=False, from_ids=True)
+            else:
+                bk = engines[0].dp_buckets
+                for i, (hi_stage, _, (lo, hi)) in enumerate(bk):
+                    lo_stage = bk[i - 1][0] if i else 0
+                    for e in engines:
+                        e._run((e.forward_ops(True, True, advance=True) if i == 0 else []) +
+                               [lambda e=e: e._run_backward(lo_stage, hi_stage), e.dp_buckets[i][1]])
+                    tot = sum(e.grads[lo:hi] for e in engines)
+                    for e in engines:
+                        e.grads[lo:hi].copy_(tot)
+                for e in engines:
+                    e._run(e.update_ops())
+                    e._wop_stale = e._fused_prologue()
+            acc[0] += sum(e.loss_out[0] for e in engines)
+            acc[1] += 1
+
+        def eval_slice(first, count):
+            for r, e in enumerate(engines):
+                load(e, ev_in, ev_out, first + r * count, count)
+                e.eval_step(use_graph=False, from_ids=True)
+            acc[2] += sum(e.loss_out[0] for e in engines)
+            acc[3] += 1
+
+        def local_sums():
+            a = acc.cpu().numpy().copy()
+            acc.zero_()
+            return a
+        e0 = engines[0]
+        snap = lambda: [e.params.clone() for e in engines]
+
+        def restore(w):
+            for e, v in zip(engines, w):
+                e.params.copy_(v)
+                e._pack_all()
+        hist = run_epochs_dp(dp, B, n_tr, n_ev, 2, train_slice, eval_slice, local_sums, e0.get_lr, e0.set_lr, snap, restore, seed=77)
+        torch.cuda.synchronize()
+        return hist, e0.get_weights()
+
+    class TwoRanksHere(DataParallel):
+        """rank 0's view; the callbacks above carry rank 1 along and hand over the SUM of both ranks' epoch sums"""
+        def __init__(self):
+            super().__init__(2, 0, 0)
+
+        def sum_over_ranks(self, values):
+            a = np.asarray(values, dtype=np.float64).copy()
+            a[1] *= 2.0                                   # (batch counts: every rank counts its own)
+            a[3] *= 2.0
+            return a
+
+        def broadcast_int(self, value):
+            return int(value)
+
+    h1, w1 = fit([engine.VAEEngine(g, B, Wv, dtype='f32', weights=params, seed=5)], DataParallel())
+    h2, w2 = fit([engine.VAEEngine(g, B // 2, Wv, dtype='f32', weights=params, seed=5, world_size=2, rank=r) for r in range(2)],
+                 TwoRanksHere())
+    assert len(h1) == len(h2) == 2
+    for a, b in zip(h1, h2):
+        assert abs(a['loss'] - b['loss']) < 1e-4 * max(1.0, abs(a['loss'])), (a, b)
+        assert abs(a['val_loss'] - b['val_loss']) < 1e-4 * max(1.0, abs(a['val_loss'])), (a, b)
+        assert a['lr'] == b['lr']
+    for k_ in w1:
+        upd = w1[k_].astype(np.float64) - params[k_]
+        assert rel_err(w2[k_].astype(np.float64) - params[k_], upd) < 5e-3, k_

@@ -342,3 +342,37 @@ def test_fit_predict_with_batch_norm(fasttext_model, corpus, tmp_path):
     res.input_embeddings = res.output_embeddings = fasttext_model
     np.testing.assert_array_equal(res.transform(corpus[0]), z1)
     assert res.predict(corpus[0][:3]) == out
+
+
+def test_best_weights_checkpoint_carries_the_batchnorm_moving_averages(fasttext_model, corpus, monkeypatch):
+    """ModelCheckpoint(save_weights_only=True, save_best_only=True) + load_weights (reference :312-316, :331-332) save and
+    restore EVERY weight of the model, the moving mean / variance of the BatchNormalization layers included: after the
+    best-epoch restore they must be those of the best epoch, not of the last one.  The fit loop is intercepted: snapshot,
+    two more training steps (which move the averages), restore."""
+    import torch
+    from conv1d_text_vae_amd import Conv1dTextVAE
+    from conv1d_text_vae_amd import estimator as est_mod
+    seen = {}
+
+    def probe(dp, B, n_tr, n_ev, max_epochs, train_slice, eval_slice, local_sums, get_lr, set_lr, snapshot, restore, **kw):
+        eng = train_slice.__closure__ and [c.cell_contents for c in train_slice.__closure__
+                                          if type(c.cell_contents).__name__ == 'VAEEngine'][0]
+        if eng.bn and 'done' not in seen:
+            first, count = dp.batch_slice(B)
+            train_slice(first, count)
+            snap = snapshot()
+            ref = {n: (st['moving_mean'].clone(), st['moving_var'].clone()) for n, st in eng.bn.items()}
+            p_ref = eng.params.clone()
+            train_slice(first, count)
+            train_slice(first, count)
+            moved = any(not torch.equal(st['moving_mean'], ref[n][0]) for n, st in eng.bn.items())
+            restore(snap)
+            seen['done'] = moved and torch.equal(eng.params, p_ref) and all(
+                torch.equal(st['moving_mean'], ref[n][0]) and torch.equal(st['moving_var'], ref[n][1]) for n, st in eng.bn.items())
+            local_sums()
+        return real(dp, B, n_tr, n_ev, max_epochs, train_slice, eval_slice, local_sums, get_lr, set_lr, snapshot, restore, **kw)
+    real = est_mod.run_epochs_dp
+    monkeypatch.setattr(est_mod, 'run_epochs_dp', probe)
+    vae = Conv1dTextVAE(fasttext_model, fasttext_model, max_epochs=2, batch_size=2, n_filters=(16,), latent_dim=8, use_batch_norm=True)
+    vae.fit(corpus[0], corpus[1])
+    assert seen.get('done') is True
