@@ -44,6 +44,11 @@ CONFIGS = {
                     'layers), per-GPU batch 2048 (global 16384 on 8 GPUs), seq_len 128, emb 300 (+2 flag slots), vocabulary '
                     '32768 rows, Nadam(clipnorm=10), bucketed RCCL all-reduce inside the captured step'),
 }
+# the reference's own demo model (demo/conv1d_text_vae_demo.py:309-312, :227, :232): n_filters=(1024, 2048), latent 700,
+# batch 128; its eng-rus corpus has <= 21 tokens per sentence and ~2.3 k distinct Russian word forms
+CONFIGS['demo'] = dict(batch=128, seq_len=21, emb=300, n_filters=(1024, 2048), kernel_size=3, latent=700, vocab_rows=2304,
+                       text='reference demo model (demo/conv1d_text_vae_demo.py:309-312): n_filters=(1024,2048) k=3 latent=700, '
+                            'batch 128, seq_len 21, emb 300 (+2 flag slots), vocabulary 2304 rows, Nadam(clipnorm=10); 24.6 M parameters')
 # BASELINE.json configs[2]: transform()/predict() inference, batch 8192, seq_len 64, 200k-word vocabulary
 CFG_PREDICT = dict(batch=8192, seq_len=64, emb=300, n_filters=(128,), kernel_size=3, latent=256, vocab_words=200000)
 # BASELINE.json configs[4]: 2M-word vocabulary over 8 GPUs = 250000 rows per GPU, batch 512, seq_len 256
@@ -51,6 +56,8 @@ CFG_PREDICT_C5 = dict(batch=512, seq_len=256, emb=300, n_filters=(128,), kernel_
 DENSE_INPUT = os.environ.get('C1V_BENCH_DENSE_INPUT', '0') == '1'     # A/B: the round-1 form of the timed input
 BF16_DENSE_PEAK_TFLOPS = 2500.0       # /opt/skills/guides/MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
 F32_MATRIX_PEAK_TFLOPS = 157.3        # same guide: fp32 MFMA
+HBM_PEAK_TBS = 8.0                    # same guide: HBM3E 8 TB/s spec (6.3 TB/s measured with a float4 copy)
+MIN_REGION_S = 0.25                   # every timed region is stretched to at least this long (inner replays)
 
 
 def gemm_flops(g, batch):
@@ -205,6 +212,56 @@ def gemm_table(eng, g, B, dtype, reps=20):
     return rows
 
 
+def hbm_table(eng, g, B, ids, reps=20):
+    """The memory-bound kernels of the step timed alone with HIP events against the HBM peak.  `bytes` = ALGORITHMIC bytes
+    of one launch (what the kernel must read and write once, from the shapes; DESIGN.md section 4 lists the formulas) --
+    not counter values: those are in profiles/r03_*_ops_pmc.json (rocprofv3 FETCH_SIZE / WRITE_SIZE per launch)."""
+    es = 2 if eng.code == 1 else 4
+    M = B * g.output_text_size
+    n_live = int((ids >= 0).sum()) if eng.compact else M
+    kp, V, Vp = eng.kp, eng.V, eng.Vp
+    ut_es = 2 if eng.ut_code == 1 else 4
+    # vocabulary splits of a live row tile as c1v_live_rows deals them (ctl[4] whole tiles with one slab, the rest ctl[2])
+    if eng.compact:
+        ctl = eng.live_ctl.cpu().numpy()
+        slab_rows = min(n_live, int(ctl[4]) * 128) + max(0, n_live - int(ctl[4]) * 128) * int(ctl[2])
+    else:
+        slab_rows = M * eng.x_splits
+    dy = eng.dOf
+    Xe = eng.Xe[0]
+    n_in_live = int((eng.in_ids >= 0).sum().item()) if getattr(eng, 'in_ids', None) is not None else B * g.input_text_size
+    rows = []
+
+    def add(name, op, nbytes, note):
+        ms = _event_ms(op, reps)
+        rows.append({'kernel': name, 'bytes': float(nbytes), 'us': ms * 1e3, 'tb_per_s': nbytes / ms / 1e9,
+                     'frac': nbytes / ms / 1e9 / HBM_PEAK_TBS, 'traffic': note})
+    slab_bytes = sum(int(t.numel()) * 4 for t in eng.slabs.values())
+    add('grad_finalize_kernel', eng.ops_finalize[0], slab_bytes + eng.P * 4, 'wgrad slabs in, flat fp32 gradient out')
+    add('nadam_kernel', [o for o in eng.update_ops() if getattr(o, '__name__', '') != 'mark_stale'][-1], eng.P * 28,
+        'p, g, m, v in; p, m, v out (28 B / parameter)')
+    core = eng.ops_loss_train_core
+    if len(core) == 3:
+        add('l2norm_rows_kernel', core[0], n_live * (Vp * 4 + kp * es + 4), 'fp32 y of the live rows in; yhat, rnorm out')
+    add('xent_finish_kernel', core[-1], slab_rows * kp * ut_es + n_live * (2 * kp * es + V * 4 + 8) + M * 4 + M * dy.cp * es,
+        'U slabs, yhat, target rows of W, fp32 y (live rows) in; dy (all rows) out')
+    if eng._input_own_launch():
+        add('live_gather_kernel (live_rows + gather_input)', eng._live_gather_op(),
+            M * 8 + B * g.input_text_size * 4 + n_in_live * eng.in_table.shape[1] * 4 + B * g.input_text_size * Xe.cp * es,
+            'target ids in, row table out; input ids + table rows in, encoder operand out')
+    else:
+        add('gather_input_kernel', eng.ops_gather_in[0], B * g.input_text_size * 4 + n_in_live * eng.in_table.shape[1] * 4 +
+            B * g.input_text_size * Xe.cp * es, 'input ids + table rows in, encoder operand out')
+        if eng.ops_live_rows:
+            add('live_rows_kernel', eng.ops_live_rows[0], M * 8, 'target ids in, row table out (latency-bound: one block)')
+    return rows
+
+
+def stretch(steps, per_step_s):
+    """inner: how often the K timed steps are replayed so that the timed region lasts at least MIN_REGION_S."""
+    return max(1, int(-(-MIN_REGION_S // max(steps * per_step_s, 1e-9))))
+
+
 def train_leg(cfg_name, dtype, dev, world, rank, steps, warmup, dist=None, force_dp=False, with_gemm_table=False,
               kernel_only=False):
     """W warm-up steps, then exactly `steps` timed steps between barriers; returns the record of rank 0 (None elsewhere)."""
@@ -234,11 +291,24 @@ def train_leg(cfg_name, dtype, dev, world, rank, steps, warmup, dist=None, force
     for _ in range(max(warmup, 2)):
         eng.train_step(all_reduce=all_reduce, from_ids=not DENSE_INPUT)
     sync()
+    # The K timed steps are replayed `inner` times back to back (same barriers around the whole region) so that the region
+    # lasts >= MIN_REGION_S: K = 20 steps of 0.2 ms are otherwise a 4 ms measurement.  `inner` comes from two probe steps and
+    # is the same on every rank (MAX over the ranks).
     t0 = time.perf_counter()
-    for _ in range(steps):
+    for _ in range(2):
         eng.train_step(all_reduce=all_reduce, from_ids=not DENSE_INPUT)
     sync()
-    elapsed = time.perf_counter() - t0
+    probe = (time.perf_counter() - t0) / 2
+    if dist is not None:
+        t = torch.tensor([probe], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        probe = float(t.item())
+    inner = stretch(steps, probe)
+    t0 = time.perf_counter()
+    for _ in range(steps * inner):
+        eng.train_step(all_reduce=all_reduce, from_ids=not DENSE_INPUT)
+    sync()
+    elapsed = (time.perf_counter() - t0) / inner
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -260,6 +330,7 @@ def train_leg(cfg_name, dtype, dev, world, rank, steps, warmup, dist=None, force
     if rank == 0:
         rec = {
             'value': B * world * steps / elapsed, 'unit': 'sequences/s', 'ms_per_step': elapsed / steps * 1e3, 'steps': steps,
+            'inner': inner, 'timed_region_s': elapsed * inner,
             'config': {'workload': cfg['text'], 'global_batch': B * world, 'per_gpu_batch': B, 'seq_len': cfg['seq_len'],
                        'vocab_rows': int(W.shape[0]), 'parallelism': 'dp%d' % world,
                        'input': 'dense fp32 [B, T, V] batch' if DENSE_INPUT else
@@ -274,6 +345,8 @@ def train_leg(cfg_name, dtype, dev, world, rank, steps, warmup, dist=None, force
                          'traffic': traffic, 'traffic_source': traffic_src, 'kernel_ms': k_ms,
                          'flops_per_launch': loss_live, 'live_row_fraction': live_frac},
         }
+        if dtype == 'bf16' and not DENSE_INPUT:
+            rec['hbm_rooflines'] = hbm_table(eng, g, B, ids)
         if with_gemm_table:
             rows = gemm_table(eng, g, B, dtype)
             rec['gemm_rooflines'] = rows
@@ -287,7 +360,7 @@ def train_leg(cfg_name, dtype, dev, world, rank, steps, warmup, dist=None, force
     return rec
 
 
-def predict_leg(dev, dtype, steps=3):
+def predict_leg(dev, dtype, steps=10):
     """Secondary metric of BASELINE.json ("predict sentences/sec"): encoder -> decoder -> EOS truncation -> nearest
     vocabulary word of every reconstructed step (fused MFMA GEMM + arg-max) on the C3 shapes, excluding tokenisation and
     the character-level generator stage.  Inputs resident in HBM."""
@@ -302,6 +375,7 @@ def predict_leg(dev, dtype, steps=3):
     words = rng.standard_normal((c['vocab_words'], c['emb']), dtype=np.float32)
     words /= np.linalg.norm(words, axis=1, keepdims=True)
     eng = engine.VAEEngine(g, B, None, dtype=dtype, device=dev, seed=7)
+    no_early_eos(eng)
     dec = engine.VocabDecoder(words, B * T, dtype=dtype, device=dev)
     x = np.zeros((B, T, V), dtype=np.float32)
     ids = rng.integers(0, c['vocab_words'], size=(B, T - 1))
@@ -317,21 +391,49 @@ def predict_leg(dev, dtype, steps=3):
 
     step()
     torch.cuda.synchronize()
+    kept = float((eng.end_idx >= T).float().mean().item())
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     flops = 2.0 * B * T * c['emb'] * c['vocab_words']
-    k_ms = _event_ms(dec.run, 1, warm=0)
+    # the arg-max kernel alone on queries that look like a trained decoder's output: vocabulary rows plus noise
+    planted_queries(dec, words, B * T, c['emb'], rng)
+    k_ms = _event_ms(dec.run, 5, warm=1)
     return {'metric': 'predict_sentences_per_sec', 'value': B / dt, 'unit': 'sentences/s', 'ms_per_batch': dt * 1e3,
+            'steps': steps, 'timed_region_s': dt * steps, 'sentences_not_truncated': kept,
             'workload': 'C3: batch 8192, seq_len 64, emb 300, 200000-word vocabulary, encoder+decoder+EOS truncation+'
                         'nearest-word GEMM/arg-max (no tokenisation, no character generator)',
+            'vocab_argmax_queries': 'vocabulary rows + 10 % Gaussian noise, unit norm (no all-zero operand rows)',
             'vocab_argmax_ms': k_ms, 'vocab_argmax_tflops': flops / (k_ms * 1e-3) / 1e12,
             'vocab_argmax_frac_of_peak': flops / (k_ms * 1e-3) / 1e12 / BF16_DENSE_PEAK_TFLOPS}
 
 
-def predict_c5_leg(dev, dtype, world, rank, dist=None, steps=3):
+def no_early_eos(eng):
+    """Random-initialised decoders declare "end of sentence" (arg-max on the last feature, reference :542-565) at a random
+    early step, after which the EOS truncation zeroes the rows -- the nearest-word GEMM would then run on mostly all-zero
+    queries (and zero operands hold a higher clock).  A trained model ends a sentence where the text ends: the bias of the
+    EOS feature of the final convolution is lowered so that no step is truncated and every query row is a dense vector."""
+    import torch
+    off = eng.seg_off['deconv_decoder_embeddings/bias'] + eng.V - 1
+    eng.params[off:off + 1].fill_(-1.0e4)
+    eng._pack_all()
+    torch.cuda.synchronize()
+
+
+def planted_queries(dec, words, M, emb, rng):
+    """M unit queries = vocabulary rows + 10 % noise (what a trained decoder emits), loaded into the decoder's operand."""
+    import numpy as np
+    import torch
+    pick = rng.integers(0, words.shape[0], size=M)
+    q = torch.from_numpy(words[pick]).to(dec.dev)
+    q = q + 0.1 * torch.randn(q.shape, device=dec.dev, generator=torch.Generator(device=dec.dev).manual_seed(5)) / float(np.sqrt(emb))
+    q = q / q.norm(dim=1, keepdim=True)
+    dec.load_queries(q)
+
+
+def predict_c5_leg(dev, dtype, world, rank, dist=None, steps=10):
     """BASELINE.json configs[4] (C5): batch 512, seq_len 256; the vocabulary is sharded by rows, 250000 per GPU (2M words on
     8 GPUs).  Every rank runs the (cheap) encoder/decoder on the whole batch, the fused GEMM + arg-max over ITS rows
     (global indices through n_base), then the (score, index) pairs are all-gathered over RCCL (8 bytes per query and rank)
@@ -352,6 +454,7 @@ def predict_c5_leg(dev, dtype, world, rank, dist=None, steps=3):
     words = rng.standard_normal((end - begin, c['emb']), dtype=np.float32)
     words /= np.linalg.norm(words, axis=1, keepdims=True)
     eng = engine.VAEEngine(g, B, None, dtype=dtype, device=dev, seed=7)
+    no_early_eos(eng)
     dec = engine.VocabDecoder(words, B * T, dtype=dtype, device=dev, n_base=begin)
     rq = np.random.Generator(np.random.PCG64(17))                       # the same batch on every rank
     x = np.zeros((B, T, V), dtype=np.float32)
@@ -397,12 +500,13 @@ def predict_c5_leg(dev, dtype, world, rank, dist=None, steps=3):
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    k_ms = _event_ms(dec.run, 2, warm=0)
+    planted_queries(dec, words, M, c['emb'], np.random.Generator(np.random.PCG64(23)))
+    k_ms = _event_ms(dec.run, 5, warm=1)
     flops = 2.0 * M * c['emb'] * (end - begin)
     del eng, dec
     torch.cuda.empty_cache()
     return {'metric': 'predict_sentences_per_sec', 'value': B / dt, 'unit': 'sentences/s', 'ms_per_batch': dt * 1e3,
-            'n_gpus': world, 'vocab_words_total': n_total, 'vocab_words_per_gpu': end - begin,
+            'steps': steps, 'timed_region_s': dt * steps, 'n_gpus': world, 'vocab_words_total': n_total, 'vocab_words_per_gpu': end - begin,
             'workload': 'C5: batch 512, seq_len 256, emb 300, vocabulary sharded by rows (250000 words per GPU; 2M on 8 GPUs): '
                         'encoder+decoder+EOS truncation+per-shard GEMM/arg-max' +
                         ('+RCCL all-gather of (score, index)+merge' if exchange else ' (one shard, no exchange at 1 GPU)'),
@@ -500,14 +604,16 @@ def main():
         return
 
     rec = train_leg(cfg_name, args.dtype, dev, world, rank, args.steps, args.warmup, dist, args.force_dp_path,
-                    with_gemm_table=(cfg_name == 'c4' and not multi))
+                    with_gemm_table=(cfg_name in ('c4', 'demo') and not multi))
     out = None
     if rank == 0:
         out = {'metric': 'train_sequences_per_sec', 'value': rec['value'], 'unit': 'sequences/s', 'n_gpus': world,
                'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': rec['ms_per_step'], 'higher_is_better': True,
                'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic', 'config': rec['config'],
                'roofline': rec['roofline']}
-        for k in ('gemm_rooflines', 'roofline_conv'):
+        out['inner'] = rec['inner']
+        out['timed_region_s'] = rec['timed_region_s']
+        for k in ('hbm_rooflines', 'gemm_rooflines', 'roofline_conv'):
             if k in rec:
                 out[k] = rec[k]
     if multi:
@@ -524,8 +630,9 @@ def main():
                 out['predict'] = p
     else:
         if cfg_name == 'c2' and not args.no_extras and not args.force_dp_path:
-            c4 = train_leg('c4', args.dtype, dev, 1, 0, max(5, args.steps // 10), 3, None, False, with_gemm_table=True)
+            c4 = train_leg('c4', args.dtype, dev, 1, 0, max(20, args.steps // 10), 3, None, False, with_gemm_table=True)
             out['c4'] = c4
+            out['demo'] = train_leg('demo', args.dtype, dev, 1, 0, max(20, args.steps // 10), 3, None, False, with_gemm_table=True)
             other = 'f32' if args.dtype == 'bf16' else 'bf16'
             r2 = train_leg('c2', other, dev, 1, 0, max(10, args.steps // 4), 5, None, False)
             fl = r2['config']['step_gflop_live']
