@@ -62,23 +62,23 @@ static int conv_params(const c1v_conv1d_args* a, const char* what, NtParams& p) 
     int64_t M = (int64_t)a->x.batch * Le;
     // Large convolutions: the wide variant (ntw_body) enumerates the FLAT buffer rows (Le = sample pitch; the rows between
     // the samples are computed and dropped by the epilogue) so that a tile's activation rows are one contiguous window,
-    // fetched once per channel strip for all taps.  OPT-IN (C1V_NTW=1: whenever it applies; C1V_NTW=auto: when the launch
-    // fills the chip with 256 x 128 tiles and at most `1 - fill` of the enumerated rows are such gaps): measured at C4
-    // (profiles/r03_c4_ntw_stamps.txt) its K loop runs at 54 % MFMA utilisation against ~30 % for the 128 x 128 kernel, but with
-    // one 256-row workgroup per CU the epilogues of all CUs fall together -- an HBM write burst nothing overlaps (19-38 k
-    // cycles per tile) -- and 4.06 rounds of tiles take 5; the two-workgroups-per-CU kernel hides both and is faster overall.
+    // fetched once per channel strip for all taps.  Taken when the launch fills the chip with two 128 x 128 workgroups per CU
+    // and at most `1 - fill` of the enumerated rows are such gaps (C1V_NTW=0 disables, =1 forces wherever it applies).
+    // C1V_NTW=2 / big selects the 256 x 128 one-workgroup-per-CU shape instead: measured at C4 (profiles/r03_c4_ntw_stamps.txt)
+    // its K loop runs at 54 % MFMA utilisation, but the epilogues of all CUs then fall together -- an HBM write burst nothing
+    // overlaps (19-38 k cycles per tile) -- and 4.06 rounds of tiles take 5.
     if (p.k_taps >= 2 && a->k <= 9 && pitch % 2 == 0 && a->x.bstride == (int64_t)pitch * a->x.cp &&
         a->epi.row_mode != C1V_ROW_LATENT_BWD) {
-        const char* env = getenv("C1V_NTW");
+        const char* env = getenv("C1V_NTW");               // 0: off; 1 / 2: force the 128-row / 256-row shape; big: 256-row by size
         const char* env_t = getenv("C1V_NTW_MIN_TILES");
         const char* env_f = getenv("C1V_NTW_MIN_FILL");
         const int64_t Mf = (int64_t)a->x.batch * pitch;
-        const int64_t tiles = c1v_cdiv(Mf, 256) * c1v_cdiv(a->n_out, 128);
-        const bool force = env && env[0] == '1', off = env && env[0] == '0';
+        const int64_t tiles = c1v_cdiv(Mf, 128) * c1v_cdiv(a->n_out, 128);
+        const bool off = env && env[0] == '0', force = env && (env[0] == '1' || env[0] == '2');
         const double fill = (double)a->n_rows / (double)pitch;
-        const bool automatic = env && env[0] == 'a';        // C1V_NTW=auto: by size (see below why that is not the default)
-        if (!off && Mf < (1ll << 31) && (force || (automatic && tiles >= (env_t ? atoll(env_t) : 224) && fill >= (env_f ? atof(env_f) : 0.70)))) {
-            p.wide = 1;
+        const bool by_size = tiles >= (env_t ? atoll(env_t) : 512) && fill >= (env_f ? atof(env_f) : 0.85);
+        if (!off && Mf < (1ll << 31) && (force || by_size)) {
+            p.wide = (env && (env[0] == '2' || env[0] == 'b')) ? 2 : 1;
             Le = pitch;
             M = Mf;
         }

@@ -121,7 +121,7 @@ struct NtParams {
     // both operands' rows: the taps of one strip are consecutive tiles, and tap j + 1 re-reads the lines tap j has just
     // fetched (the same buffer rows, shifted by one) while they are still in the XCD's L2.  k_taps <= 1: natural order.
     int k_taps, k_strips;
-    int wide;                                                         // ntw_body: 256 x 128 tiles over the flat buffer rows (e.Le = sample pitch)
+    int wide;                                                         // ntw_body over the flat buffer rows (e.Le = sample pitch): 1 = 128 x 128 (two workgroups per CU), 2 = 256 x 128
     EpiDev e;
 };
 

@@ -16,13 +16,20 @@ __global__ __launch_bounds__(C1V_GEMM_THREADS, 3) void gemm_nt_large_kernel(cons
     xcd_tile(blockIdx.x, (p.e.M + 127) >> 7, (p.e.N + 127) >> 7, bx, by);
     nt_body<T, 128, 128, NS, false>(p, bx, by, blockIdx.x, 0);
 }
-// wide variant (ntw_body): a linear grid dealt to (row tile, column tile) by xcd_tile(), one workgroup per CU
+// window variants (ntw_body): a linear grid dealt to (row tile, column tile) by xcd_tile()
 template <typename T, int MODE>
 __global__ __launch_bounds__(C1V_GEMM_THREADS) void gemm_ntw_kernel(const NtParams p) {
     c1v_touch_kernarg<4>();
     int bx, by;
-    xcd_tile(blockIdx.x, (p.e.M + NTW_BM - 1) / NTW_BM, (p.e.N + NTW_BN - 1) / NTW_BN, bx, by);
-    ntw_body<T, MODE>(p, bx, by);
+    xcd_tile(blockIdx.x, (p.e.M + NtwBig::BM - 1) / NtwBig::BM, (p.e.N + NtwBig::BN - 1) / NtwBig::BN, bx, by);
+    ntw_body<T, MODE, NtwBig>(p, bx, by);
+}
+template <typename T, int MODE>
+__global__ __launch_bounds__(C1V_GEMM_THREADS, 3) void gemm_ntw2_kernel(const NtParams p) {
+    c1v_touch_kernarg<4>();
+    int bx, by;
+    xcd_tile(blockIdx.x, (p.e.M + NtwTwo::BM - 1) / NtwTwo::BM, (p.e.N + NtwTwo::BN - 1) / NtwTwo::BN, bx, by);
+    ntw_body<T, MODE, NtwTwo>(p, bx, by);
 }
 template <typename T>
 __global__ __launch_bounds__(C1V_GEMM_THREADS) void gemm_tn_kernel(const TnParams p) {
@@ -73,9 +80,15 @@ template <typename T> static void launch_nt_large(const NtParams& p, hipStream_t
 }
 
 template <typename T, int MODE> static void launch_ntw_m(const NtParams& p, hipStream_t st) {
-    static bool once = (set_lds(gemm_ntw_kernel<T, MODE>, NTW_LDS), true); (void)once;
-    dim3 grid((unsigned)(c1v_cdiv(p.e.M, NTW_BM) * c1v_cdiv(p.e.N, NTW_BN)), 1, 1);
-    hipLaunchKernelGGL((gemm_ntw_kernel<T, MODE>), grid, dim3(C1V_GEMM_THREADS), NTW_LDS, st, p);
+    if (p.wide == 2) {
+        static bool once = (set_lds(gemm_ntw_kernel<T, MODE>, NtwBig::LDS), true); (void)once;
+        dim3 grid((unsigned)(c1v_cdiv(p.e.M, NtwBig::BM) * c1v_cdiv(p.e.N, NtwBig::BN)), 1, 1);
+        hipLaunchKernelGGL((gemm_ntw_kernel<T, MODE>), grid, dim3(C1V_GEMM_THREADS), NtwBig::LDS, st, p);
+    } else {
+        static bool once = (set_lds(gemm_ntw2_kernel<T, MODE>, NtwTwo::LDS), true); (void)once;
+        dim3 grid((unsigned)(c1v_cdiv(p.e.M, NtwTwo::BM) * c1v_cdiv(p.e.N, NtwTwo::BN)), 1, 1);
+        hipLaunchKernelGGL((gemm_ntw2_kernel<T, MODE>), grid, dim3(C1V_GEMM_THREADS), NtwTwo::LDS, st, p);
+    }
 }
 template <typename T> static void launch_ntw(const NtParams& p, hipStream_t st) {
     switch (p.e.row_mode) {

@@ -718,28 +718,41 @@ __device__ __forceinline__ void nt_body(const NtParams& p, const int bx, const i
 // four MFMAs ahead of their use (sched_barrier(0) pins the order: with one wave per SIMD nothing else hides LDS latency).
 // Results are bit-identical to nt_body's (same products, same order of the K tiles).
 // ------------------------------------------------------------------------------------------------------
-constexpr int NTW_BM = 256, NTW_BN = 128;
-constexpr int NTW_AROWS = NTW_BM + 8;                  // window rows: the tile's rows + up to 8 rows of halo (k <= 9)
-constexpr int NTW_A_STAGE = NTW_AROWS * 128;
-constexpr int NTW_W_STAGE = NTW_BN * 128;
-constexpr int NTW_NSA = 2, NTW_NSW = 5;
-constexpr int NTW_RING = NTW_NSA * NTW_A_STAGE + NTW_NSW * NTW_W_STAGE;
-constexpr int NTW_LDC = NTW_BN + 4;
-constexpr int NTW_LDS = NTW_RING > NTW_BM * NTW_LDC * 4 ? NTW_RING : NTW_BM * NTW_LDC * 4;
-static_assert(NTW_LDS <= 160 * 1024, "one workgroup per CU");
+// Two shapes of it (NtwCfg):
+//   NtwBig  256 x 128 tile, waves 4 x 1 (64 x 128 each), weight ring of 5 with look-ahead (barrier t promises tile t+1), one
+//           workgroup per CU.  Opt-in (C1V_NTW=big): its epilogues fall together on all CUs (see c1v_api.hip).
+//   NtwTwo  128 x 128 tile, waves 2 x 2 (64 x 64 each), two-stage weight ring, <= 168 registers and 66 KiB of LDS: TWO
+//           workgroups per CU that hide each other's epilogue and ring latency, like nt_body's large variant, but with a
+//           third less to take in per K tile.
+template <int BM_, int BN_, int WGM_, int WGN_, int NSW_, bool LOOK_>
+struct NtwCfg {
+    static constexpr int BM = BM_, BN = BN_, WGM = WGM_, WGN = WGN_, NSW = NSW_, NSA = 2;
+    static constexpr bool LOOK = LOOK_;
+    static constexpr int MI = BM / WGM / 16, NJ = BN / WGN / 16;
+    static constexpr int AROWS = BM + 8;                   // window rows: the tile's rows + up to 8 rows of halo (k <= 9)
+    static constexpr int A_STAGE = AROWS * 128, W_STAGE = BN * 128;
+    static constexpr int RING = NSA * A_STAGE + NSW * W_STAGE;
+    static constexpr int LDC = BN + 4;
+    static constexpr int LDS = RING > BM * LDC * 4 ? RING : BM * LDC * 4;
+    static constexpr int IPA = AROWS / 8, IPW = BN / 8;
+    static_assert(WGM * WGN == 4 && MI <= NJ && NJ % 2 == 0 && AROWS % 8 == 0, "wave grid");
+    static_assert(IPA <= 63 && (NSW - 2) * IPW <= 63 && LDS <= 160 * 1024, "vmcnt is a 6-bit counter; LDS of a CU");
+};
+using NtwBig = NtwCfg<256, 128, 4, 1, 5, true>;
+using NtwTwo = NtwCfg<128, 128, 2, 2, 2, false>;
 
-template <typename T, int MODE>
+template <typename T, int MODE, typename Cfg>
 __device__ __forceinline__ void ntw_body(const NtParams& p, const int bx, const int by) {
 #ifdef NT_STAMP
     unsigned long long stamp[16];
 #endif
     NT_T(0);
-    constexpr int BM = NTW_BM, BN = NTW_BN, MI = 4, NJ = 8;
-    constexpr int IPA = NTW_AROWS / 8, IPW = BN / 8;
-    static_assert(IPA <= 63 && 2 * IPW <= 63, "vmcnt is a 6-bit counter");
+    constexpr int BM = Cfg::BM, BN = Cfg::BN, MI = Cfg::MI, NJ = Cfg::NJ, NSW = Cfg::NSW;
+    constexpr int IPA = Cfg::IPA, IPW = Cfg::IPW;
+    constexpr bool LOOK = Cfg::LOOK;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const sA = smem;
-    char* const sW = smem + NTW_NSA * NTW_A_STAGE;
+    char* const sW = smem + Cfg::NSA * Cfg::A_STAGE;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -752,7 +765,7 @@ __device__ __forceinline__ void ntw_body(const NtParams& p, const int bx, const 
     if (wave >= 4) {
         const int prow = lane >> 3, ppos = lane & 7;
         if (wave == 4) {
-            // ---- activation windows: buffer rows a_off + m0 + [0, NTW_AROWS), clamped into the allocation (rows past the
+            // ---- activation windows: buffer rows a_off + m0 + [0, AROWS), clamped into the allocation (rows past the
             // last sample only feed GEMM rows >= M, which the epilogue drops)
             const int64_t lim = (int64_t)ev.M + C1V_SLACK_ROWS - 1;
             const char* src[IPA];
@@ -764,7 +777,7 @@ __device__ __forceinline__ void ntw_body(const NtParams& p, const int bx, const 
                 src[i] = p.A + r * p.lda_b + ((ppos ^ ((row >> 1) & 7)) << 4);
             }
             auto issue = [&](int s) {
-                char* d = sA + (s & 1) * NTW_A_STAGE;
+                char* d = sA + (s & 1) * Cfg::A_STAGE;
                 const int64_t ko = (int64_t)s * 128;
 #pragma unroll
                 for (int i = 0; i < IPA; ++i) glds16(src[i] + ko, d + i * 1024);
@@ -773,16 +786,17 @@ __device__ __forceinline__ void ntw_body(const NtParams& p, const int bx, const 
             if (strips > 1) issue(1);
             int tap = 0, s = 0;                            // tile t = (strip s, tap)
             for (int t = 0; t < KT; ++t) {
-                // barrier t promises the window of tile t+1: strip 0 at t = 0, afterwards a new strip whenever tile t+1 is a tap 0
+                // barrier t promises the window of tile t (LOOK: of tile t+1): strip 0 at t = 0, afterwards a new strip
+                // whenever that tile is a tap 0
                 if (t == 0) { if (strips > 1) wait_vmcnt<IPA>(); else wait_vmcnt<0>(); }
-                else if (tap == taps - 1) wait_vmcnt<0>();
+                else if (LOOK ? tap == taps - 1 : tap == 0) wait_vmcnt<0>();
                 block_barrier();
                 // everybody is done with tile t-1: at the first tile of strip s >= 1 the stage of strip s-1 is free for s+1
                 if (tap == 0 && s >= 1 && s + 1 < strips) issue(s + 1);
                 if (++tap == taps) { tap = 0; ++s; }
             }
         } else {
-            // ---- weight tiles: rows n0 + [0, 128), K tile t = (strip t / taps, tap t % taps) at byte offset tap*k_strips*128 + strip*128
+            // ---- weight tiles: rows n0 + [0, BN), K tile t = (strip t / taps, tap t % taps) at byte offset tap*k_strips*128 + strip*128
             const char* src[IPW];
 #pragma unroll
             for (int i = 0; i < IPW; ++i) {
@@ -795,19 +809,24 @@ __device__ __forceinline__ void ntw_body(const NtParams& p, const int bx, const 
             int64_t ko = 0;
             const int64_t tap_b = (int64_t)strips * 128;
             auto issue = [&](int kt) {
-                char* d = sW + (kt % NTW_NSW) * NTW_W_STAGE;
+                char* d = sW + (kt % NSW) * Cfg::W_STAGE;
 #pragma unroll
                 for (int i = 0; i < IPW; ++i) glds16(src[i] + ko, d + i * 1024);
                 if (++tap_i == taps) { tap_i = 0; ko += 128 - (int64_t)(taps - 1) * tap_b; } else ko += tap_b;
             };
 #pragma unroll
-            for (int t = 0; t < NTW_NSW - 1; ++t)
+            for (int t = 0; t < NSW - 1; ++t)
                 if (t < KT) issue(t);
             for (int t = 0; t < KT; ++t) {
-                // issued so far: tiles < min(KT, t + NSW - 1); tiles <= t+1 must have landed
-                if (t + 4 <= KT) wait_vmcnt<2 * IPW>(); else if (t + 3 == KT) wait_vmcnt<IPW>(); else wait_vmcnt<0>();
-                block_barrier();                           // everybody is done with tile t-1: its stage takes tile t+4
-                if (t + NTW_NSW - 1 < KT) issue(t + NTW_NSW - 1);
+                // issued so far: tiles < min(KT, t + NSW - 1); tiles <= `need` must have landed
+                const int issued = t + NSW - 1 < KT ? t + NSW - 1 : KT;
+                const int need = (LOOK && t + 1 < KT) ? t + 1 : t;
+                const int out = issued - 1 - need;         // tiles that may still be in flight
+                if (out >= 2) wait_vmcnt<(NSW >= 5 ? 2 : 0) * IPW>();
+                else if (out == 1) wait_vmcnt<(NSW >= 4 || (NSW >= 3 && !LOOK) ? 1 : 0) * IPW>();
+                else wait_vmcnt<0>();
+                block_barrier();                           // everybody is done with tile t-1: its stage takes tile t+NSW-1
+                if (t + NSW - 1 < KT) issue(t + NSW - 1);
             }
         }
         block_barrier();                                   // the two barriers of the epilogue below
@@ -839,44 +858,52 @@ __device__ __forceinline__ void ntw_body(const NtParams& p, const int bx, const 
         }
     }
 
-    // fragment addresses: A fragment i of tap j = window row 64 wave + 16 i + (lane & 15) + j, chunk kk*4 + (lane >> 4); the
-    // swizzle depends on the row through (row >> 1) & 7 only, which the + 16 i and + 64 wave steps leave alone, and the
-    // second half of the K tile (kk = 1) is the first one's address with bit 6 flipped
+    // fragment addresses: A fragment i of tap j = window row (wave's first row) + 16 i + (lane & 15) + j, chunk kk*4 + (lane >> 4);
+    // the swizzle depends on the row through (row >> 1) & 7 only, which steps of 16 rows leave alone, and the second half of
+    // the K tile (kk = 1) is the first one's address with bit 6 flipped
     const int fr = lane & 15, fc = lane >> 4;
+    const int wm = wave / Cfg::WGN, wn = wave - wm * Cfg::WGN;
     // (byte offsets from `smem`; every stage offset is a multiple of 128, so bit 6 belongs to the chunk index)
-    const int a_wave = wave * 64 * 128;
-    const int b_lane = NTW_NSA * NTW_A_STAGE + lds_off(fr, fc);
-    auto a_addr = [&](int s, int tap) -> int { return (s & 1) * NTW_A_STAGE + a_wave + lds_off(fr + tap, fc); };
-    auto b_addr = [&](int t) -> int { return (t % NTW_NSW) * NTW_W_STAGE + b_lane; };
+    const int a_wave = wm * (BM / Cfg::WGM) * 128;
+    const int b_lane = Cfg::NSA * Cfg::A_STAGE + wn * (BN / Cfg::WGN) * 128 + lds_off(fr, fc);
+    auto a_addr = [&](int s, int tap) -> int { return (s & 1) * Cfg::A_STAGE + a_wave + lds_off(fr + tap, fc); };
+    auto b_addr = [&](int t) -> int { return (t % NSW) * Cfg::W_STAGE + b_lane; };
     auto ld = [&](int base, int frag, int kk) -> uint4 { return *(const uint4*)(smem + ((base ^ (kk * 64)) + frag * 16 * 128)); };
 
     uint4 af[2][MI], bf[4];
     NT_T(1);
-    block_barrier();                                       // barrier 0: tiles 0 and 1 are in LDS
-    NT_T(7);
-    {
+    if constexpr (LOOK) {
+        block_barrier();                                   // barrier 0: tiles 0 and 1 are in LDS
         const int a0 = a_addr(0, 0), b0 = b_addr(0);
 #pragma unroll
         for (int i = 0; i < MI; ++i) af[0][i] = ld(a0, i, 0);
 #pragma unroll
         for (int j = 0; j < 3; ++j) bf[j] = ld(b0, j, 0);
     }
+    NT_T(7);
     int tap = 0, s = 0;
     for (int t = 0; t < KT; ++t) {
         const int a_cur = a_addr(s, tap), b_cur = b_addr(t);
         int tapn = tap + 1, sn = s;
         if (tapn == taps) { tapn = 0; ++sn; }
-        const bool more = t + 1 < KT;                      // wave-uniform
+        const bool more = LOOK && t + 1 < KT;              // wave-uniform
         const int a_nxt = a_addr(sn, tapn), b_nxt = b_addr(t + 1);
+        if constexpr (!LOOK) {
+            block_barrier();                               // barrier t: tile t is in LDS
+#pragma unroll
+            for (int i = 0; i < MI; ++i) af[0][i] = ld(a_cur, i, 0);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) bf[j] = ld(b_cur, j, 0);
+        }
 #pragma unroll
         for (int g = 0; g < 2 * NJ; ++g) {
-            const int kk = g >> 3, j = g & 7;
+            const int kk = g / NJ, j = g % NJ;
             // reads that run ahead: the weight fragment of group g+3 and, one per group, the activation fragments of the
-            // next half tile (groups 0-3: kk = 1 of this tile; groups 8-11: kk = 0 of the next tile, which barrier t has
-            // promised)
+            // next half tile (groups 0..MI-1: kk = 1 of this tile; groups NJ..NJ+MI-1, LOOK only: kk = 0 of the next tile,
+            // which barrier t has promised)
             const int gn = g + 3;
-            if (gn < 2 * NJ) bf[gn & 3] = ld(b_cur, gn & 7, gn >> 3);
-            else if (more) bf[gn & 3] = ld(b_nxt, gn & 7, 0);
+            if (gn < 2 * NJ) bf[gn & 3] = ld(b_cur, gn % NJ, gn / NJ);
+            else if (more) bf[gn & 3] = ld(b_nxt, gn - 2 * NJ, 0);
             if (g < MI) af[1][g] = ld(a_cur, g, 1);
             else if (g >= NJ && g < NJ + MI && more) af[0][g - NJ] = ld(a_nxt, g - NJ, 0);
             __builtin_amdgcn_sched_barrier(0);
@@ -888,7 +915,7 @@ __device__ __forceinline__ void ntw_body(const NtParams& p, const int bx, const 
         if (more) block_barrier();                         // barrier t+1
     }
 
-    // ---- epilogue through LDS (see nt_body): the 256 x 128 tile parked as fp32, walked by rows
+    // ---- epilogue through LDS (see nt_body): the tile parked as fp32, walked by rows
     NT_T(2);
     float* ct = (float*)smem;
     block_barrier();                                       // every wave is done reading the last operand stages
@@ -899,13 +926,12 @@ __device__ __forceinline__ void ntw_body(const NtParams& p, const int bx, const 
         for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                ct[(wave * 64 + i * 16 + (lane >> 4) * 4 + r) * NTW_LDC + j * 16 + (lane & 15)] = acc[i][j][r];
+                ct[(wm * (BM / Cfg::WGM) + i * 16 + (lane >> 4) * 4 + r) * Cfg::LDC + wn * (BN / Cfg::WGN) + j * 16 + (lane & 15)] = acc[i][j][r];
     block_barrier();
     NT_T(5);
     // (one row mode per instantiation, 4-wide vector epilogue only -- the host takes this variant for such launches only: with
-    // every mode in one kernel the epilogue was 26 k instructions of straight-line code and ~3 k SGPR spill moves, and with one
-    // workgroup per CU nothing overlaps it)
-    epi_seq_rows<BM, BN, MODE, 4>(ev, rd, ct, NTW_LDC, m0, n0, tid, bias4);
+    // every mode in one kernel the epilogue was 26 k instructions of straight-line code and ~3 k SGPR spill moves)
+    epi_seq_rows<BM, BN, MODE, 4>(ev, rd, ct, Cfg::LDC, m0, n0, tid, bias4);
 #ifdef NT_STAMP
     NT_T(6);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

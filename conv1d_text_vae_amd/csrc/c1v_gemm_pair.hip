@@ -45,6 +45,40 @@ __global__ __launch_bounds__(C1V_GEMM_THREADS, 3) void gemm_pair_large_kernel(co
     }
 }
 
+// the same with the window variant of the dgrad tiles (ntw_body, 128 x 128, two workgroups per CU; one row mode per
+// instantiation)
+template <typename T, int MODE>
+__global__ __launch_bounds__(C1V_GEMM_THREADS, 3) void gemm_pair_ntw_kernel(const PairParams pp) {
+    c1v_touch_kernarg<7>();
+    const int id = blockIdx.x;
+    if (id < pp.tn_blocks) {
+        const int bz = id / pp.tn_gij, r = id - bz * pp.tn_gij;
+        const int by = r / pp.tn_gi, bx = r - by * pp.tn_gi;
+        tn_body<T>(pp.tn, bx, by, bz);
+    } else {
+        const int r = id - pp.tn_blocks;
+        int bx, by;
+        xcd_tile(r, pp.nt_gm, (pp.nt.e.N + NtwTwo::BN - 1) / NtwTwo::BN, bx, by);
+        ntw_body<T, MODE, NtwTwo>(pp.nt, bx, by);
+    }
+}
+template <typename T, int MODE> static void launch_pair_ntw_m(PairParams& pp, hipStream_t st) {
+    constexpr int LDS = NtwTwo::LDS > TN_LDS ? NtwTwo::LDS : TN_LDS;
+    static bool once = (set_lds(gemm_pair_ntw_kernel<T, MODE>, LDS), true); (void)once;
+    pp.nt_gm = (int)c1v_cdiv(pp.nt.e.M, NtwTwo::BM);
+    const int64_t nt_blocks = (int64_t)pp.nt_gm * c1v_cdiv(pp.nt.e.N, NtwTwo::BN);
+    hipLaunchKernelGGL((gemm_pair_ntw_kernel<T, MODE>), dim3((unsigned)(pp.tn_blocks + nt_blocks)), dim3(C1V_GEMM_THREADS), LDS, st, pp);
+}
+template <typename T> static void launch_pair_ntw(PairParams& pp, hipStream_t st) {
+    switch (pp.nt.e.row_mode) {
+        case C1V_ROW_STORE:   launch_pair_ntw_m<T, C1V_ROW_STORE>(pp, st); break;
+        case C1V_ROW_POOL2:   launch_pair_ntw_m<T, C1V_ROW_POOL2>(pp, st); break;
+        case C1V_ROW_UP2:     launch_pair_ntw_m<T, C1V_ROW_UP2>(pp, st); break;
+        case C1V_ROW_PAIRSUM: launch_pair_ntw_m<T, C1V_ROW_PAIRSUM>(pp, st); break;
+        default:              launch_pair_ntw_m<T, C1V_ROW_UNPOOL>(pp, st); break;
+    }
+}
+
 template <typename T, int NS> static void launch_pair_large_ns(PairParams& pp, hipStream_t st) {
     constexpr int NT_LDS = nt_lds<128, 128, NS>();
     constexpr int LDS = NT_LDS > TN_LDS ? NT_LDS : TN_LDS;
@@ -71,6 +105,11 @@ template <typename T, int BM, int BN, int NS> static void launch_pair_v(PairPara
 }
 
 template <typename T> static int launch_pair_t(PairParams& pp, hipStream_t st) {
+    if (pp.nt.wide == 1) {
+        launch_pair_ntw<T>(pp, st);
+        C1V_LAUNCH_CHECK();
+        return 0;
+    }
     switch (nt_variant(pp.nt)) {
         case NT_128L:    launch_pair_large<T>(pp, st); break;
         case NT_128:     launch_pair_v<T, 128, 128, 3>(pp, st); break;
@@ -83,7 +122,7 @@ template <typename T> static int launch_pair_t(PairParams& pp, hipStream_t st) {
 int c1v_launch_pair(int dtype, const NtParams& nt, const TnParams& tn, hipStream_t st) {
     if (c1v_check_nt(nt) || c1v_check_tn(tn)) return -1;
     C1V_REQUIRE(nt.ksplits <= 1, "pair launch: split-K dgrad is not supported");
-    if (nt.wide || tn.tg >= 2) {
+    if (nt.wide == 2 || tn.tg >= 2) {
         // the large-batch variants (one workgroup per CU each: 256 x 128 dgrad tiles, fused-tap wgrad) fill the chip by
         // themselves: two launches, wgrad first
         if (c1v_launch_tn(dtype, tn, st)) return -1;

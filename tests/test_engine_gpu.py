@@ -230,18 +230,19 @@ def test_wide_window_nt_variant_is_bit_identical(name, dtype, monkeypatch):
     c = CASES[name]
     og, params, Wv, x, ids, eps, mask_e, mask_d = make_case(c)
     got = {}
-    for mode in ('1', '0'):
+    for mode in ('1', '2', '0'):                 # 128 x 128 (two workgroups per CU) | 256 x 128 (one) | the plain kernels
         monkeypatch.setenv('C1V_NTW', mode)
         eng = build_engine(c, og, params, Wv, dtype)
         load_fixed(eng, x, ids, eps, mask_e, mask_d)
         eng._run(eng.train_ops(False))
         torch.cuda.synchronize()
         got[mode] = (eng.get_grads(), eng.loss(), eng.y_pred().cpu().numpy(), eng.mlv.cpu().numpy())
-    assert got['1'][1] == got['0'][1]
-    np.testing.assert_array_equal(got['1'][2], got['0'][2])
-    np.testing.assert_array_equal(got['1'][3], got['0'][3])
-    for k_, v in got['0'][0].items():
-        np.testing.assert_array_equal(got['1'][0][k_], v, err_msg=k_)
+    for mode in ('1', '2'):
+        assert got[mode][1] == got['0'][1]
+        np.testing.assert_array_equal(got[mode][2], got['0'][2])
+        np.testing.assert_array_equal(got[mode][3], got['0'][3])
+        for k_, v in got['0'][0].items():
+            np.testing.assert_array_equal(got[mode][0][k_], v, err_msg=k_)
 
 
 @pytest.mark.parametrize('dtype', ['f32', 'bf16'])
