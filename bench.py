@@ -241,6 +241,12 @@ def hbm_table(eng, g, B, ids, reps=20):
     add('nadam_kernel', [o for o in eng.update_ops() if getattr(o, '__name__', '') != 'mark_stale'][-1], eng.P * 28,
         'p, g, m, v in; p, m, v out (28 B / parameter)')
     core = eng.ops_loss_train_core
+    if eng.fuse_norm:
+        Xf = eng.Xf
+        add('gemm_ntw_row_kernel (out_conv fwd + l2norm)', eng.ops_dec[-1],
+            B * Xf.pitch * Xf.cp * es + n_live * (Vp * 4 + kp * es + 4) + M * 4,
+            'decoder activations in (every buffer row once); fp32 y, yhat, rnorm of the live rows out -- a GEMM launch, listed '
+            'here because its length is its stores')
     if len(core) == 3:
         add('l2norm_rows_kernel', core[0], n_live * (Vp * 4 + kp * es + 4), 'fp32 y of the live rows in; yhat, rnorm out')
     add('xent_finish_kernel', core[-1], slab_rows * kp * ut_es + n_live * (2 * kp * es + V * 4 + 8) + M * 4 + M * dy.cp * es,

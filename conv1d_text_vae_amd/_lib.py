@@ -15,7 +15,7 @@ BF16 = 1
 SLACK_ROWS = 72
 CHUNK = 2048
 PACK_TILE = 64          # C1V_PACK_TILE
-ROW_STORE, ROW_POOL2, ROW_UP2, ROW_PAIRSUM, ROW_UNPOOL, ROW_LATENT_BWD = 0, 1, 2, 3, 4, 5
+ROW_STORE, ROW_POOL2, ROW_UP2, ROW_PAIRSUM, ROW_UNPOOL, ROW_LATENT_BWD, ROW_NORM = 0, 1, 2, 3, 4, 5, 6
 
 
 def fused_width(kp: int) -> bool:
@@ -34,7 +34,9 @@ class Epilogue(C.Structure):
                 ('sel', C.c_void_p), ('sel_bstride', C.c_int64), ('sel_cp', C.c_int32),
                 ('keep', C.c_void_p), ('keep_scale', C.c_float),
                 ('lat_mlv', C.c_void_p), ('lat_eps', C.c_void_p), ('lat_keep', C.c_void_p), ('lat_D', C.c_int32),
-                ('lat_keep_prob', C.c_float), ('lat_std_scale', C.c_float), ('lat_kc', C.c_float), ('bias_row_w', C.c_int32)]
+                ('lat_keep_prob', C.c_float), ('lat_std_scale', C.c_float), ('lat_kc', C.c_float), ('bias_row_w', C.c_int32),
+                ('nrm_yhat', C.c_void_p), ('nrm_kp', C.c_int32), ('nrm_rnorm', C.c_void_p), ('nrm_qscale', C.c_float),
+                ('nrm_pos', C.c_void_p), ('nrm_live_only', C.c_int32)]
 
 
 class ConvArgs(C.Structure):

@@ -83,8 +83,16 @@ static int conv_params(const c1v_conv1d_args* a, const char* what, NtParams& p) 
             M = Mf;
         }
     }
+    if (a->epi.row_mode == C1V_ROW_NORM) {                // whole rows in one workgroup: the flat-row enumeration at any size
+        C1V_REQUIRE(p.k_taps >= 2 && a->k <= 9 && a->x.bstride == (int64_t)pitch * a->x.cp,
+                    "%s: ROW_NORM needs 2..9 taps over whole 128-byte channel strips and samples one after the other", what);
+        p.wide = 3;
+        Le = pitch;
+        M = (int64_t)a->x.batch * pitch;
+    }
     C1V_REQUIRE(M < (1ll << 31), "%s: too many rows", what);
     if (c1v_fill_epi(a->epi, p.e, (int)M, Le, a->n_rows, a->n_out)) return -1;
+    if (p.wide == 3) { p.e.nrm_T = a->x.dtype; return 0; }
     if (p.wide && p.e.fastw != 4) {                      // the wide variant only comes with the 4-wide vector epilogue
         p.wide = 0;
         Le = pairs ? ((a->n_rows + 1) & ~1) : a->n_rows;

@@ -31,6 +31,12 @@ __global__ __launch_bounds__(C1V_GEMM_THREADS, 3) void gemm_ntw2_kernel(const Nt
     xcd_tile(blockIdx.x, (p.e.M + NtwTwo::BM - 1) / NtwTwo::BM, (p.e.N + NtwTwo::BN - 1) / NtwTwo::BN, bx, by);
     ntw_body<T, MODE, NtwTwo>(p, bx, by);
 }
+// whole output rows + l2 normalisation (NtwRow / C1V_ROW_NORM): one column tile, row tiles in launch order
+template <typename T, typename Cfg>
+__global__ __launch_bounds__(C1V_GEMM_THREADS) void gemm_ntw_row_kernel(const NtParams p) {
+    c1v_touch_kernarg<4>();
+    ntw_body<T, C1V_ROW_NORM, Cfg>(p, blockIdx.x, 0);
+}
 template <typename T>
 __global__ __launch_bounds__(C1V_GEMM_THREADS) void gemm_tn_kernel(const TnParams p) {
     tn_body<T>(p, blockIdx.x, blockIdx.y, blockIdx.z);
@@ -91,6 +97,18 @@ template <typename T, int MODE> static void launch_ntw_m(const NtParams& p, hipS
     }
 }
 template <typename T> static void launch_ntw(const NtParams& p, hipStream_t st) {
+    if (p.wide == 3) {
+        // fewer 128-row tiles than CUs: 64-row tiles instead (twice the workgroups, each stores half as much; the launch
+        // is one round of tiles either way and its length is the stores of one workgroup)
+        if (c1v_cdiv(p.e.M, NtwRow::BM) < 256) {
+            static bool once = (set_lds(gemm_ntw_row_kernel<T, NtwRowS>, NtwRowS::LDS), true); (void)once;
+            hipLaunchKernelGGL((gemm_ntw_row_kernel<T, NtwRowS>), dim3((unsigned)c1v_cdiv(p.e.M, NtwRowS::BM)), dim3(C1V_GEMM_THREADS), NtwRowS::LDS, st, p);
+        } else {
+            static bool once = (set_lds(gemm_ntw_row_kernel<T, NtwRow>, NtwRow::LDS), true); (void)once;
+            hipLaunchKernelGGL((gemm_ntw_row_kernel<T, NtwRow>), dim3((unsigned)c1v_cdiv(p.e.M, NtwRow::BM)), dim3(C1V_GEMM_THREADS), NtwRow::LDS, st, p);
+        }
+        return;
+    }
     switch (p.e.row_mode) {
         case C1V_ROW_STORE:   launch_ntw_m<T, C1V_ROW_STORE>(p, st); break;
         case C1V_ROW_POOL2:   launch_ntw_m<T, C1V_ROW_POOL2>(p, st); break;
@@ -125,9 +143,10 @@ int c1v_check_nt(const NtParams& p) {
     C1V_REQUIRE(!pairs || (p.e.Le % 2 == 0), "pair epilogue needs an even row enumeration (Le=%d)", p.e.Le);
     if (p.wide)
         C1V_REQUIRE(p.k_taps >= 2 && p.k_taps <= 9 && p.k_strips >= 1 && p.Kb == (int64_t)p.k_taps * p.k_strips * 128 && p.ksplits <= 1 &&
-                    p.e.row_mode != C1V_ROW_LATENT_BWD && p.e.fastw == 4,
+                    p.e.row_mode != C1V_ROW_LATENT_BWD && (p.wide == 3 ? p.e.N <= NtwRow::BN : p.e.fastw == 4),
                     "wide NT variant: needs a convolution over whole 128-byte channel strips (taps %d, strips %d, K %lld bytes)",
                     p.k_taps, p.k_strips, (long long)p.Kb);
+    C1V_REQUIRE((p.e.row_mode == C1V_ROW_NORM) == (p.wide == 3), "ROW_NORM comes with the whole-row variant only (convolutions over whole 128-byte channel strips)");
     if (p.ksplits > 1) {
         C1V_REQUIRE(p.e.row_mode == C1V_ROW_STORE && !p.e.relu && !p.e.exp2 && p.e.act == nullptr && p.e.keep == nullptr,
                     "split-K needs a plain STORE epilogue (partial sums are not final values)");
@@ -184,8 +203,19 @@ int c1v_fill_epi(const c1v_epilogue& e, EpiDev& d, int M, int Le, int nrows, int
     d.lat_mlv = e.lat_mlv; d.lat_eps = e.lat_eps; d.lat_keep = e.lat_keep; d.lat_D = e.lat_D;
     d.lat_keep_prob = e.lat_keep_prob; d.lat_std_scale = e.lat_std_scale; d.lat_kc = e.lat_kc;
     d.M = M; d.Le = Le; d.nrows = nrows; d.N = N;
+    d.nrm_yhat = e.nrm_yhat; d.nrm_kp = e.nrm_kp; d.nrm_rnorm = e.nrm_rnorm; d.nrm_qscale = e.nrm_qscale; d.nrm_pos = e.nrm_pos;
+    d.nrm_live_only = e.nrm_live_only; d.nrm_T = 0;
     C1V_REQUIRE(e.dst.data != nullptr, "epilogue has no destination");
-    C1V_REQUIRE(e.row_mode >= C1V_ROW_STORE && e.row_mode <= C1V_ROW_LATENT_BWD, "bad row_mode %d", e.row_mode);
+    C1V_REQUIRE(e.row_mode >= C1V_ROW_STORE && e.row_mode <= C1V_ROW_NORM, "bad row_mode %d", e.row_mode);
+    if (e.row_mode == C1V_ROW_NORM) {
+        C1V_REQUIRE(e.nrm_yhat && e.nrm_rnorm && e.nrm_kp >= N && e.nrm_kp % 8 == 0 && e.nrm_kp <= 320, "ROW_NORM: needs yhat, rnorm and n_out <= nrm_kp <= 320");
+        C1V_REQUIRE(!e.relu && e.act.data == nullptr && e.keep == nullptr && e.sel == nullptr && e.reshape_w <= 0 && e.dst.dtype == C1V_F32,
+                    "ROW_NORM: a plain fp32 STORE epilogue (bias only)");
+        C1V_REQUIRE(e.dst.cp <= 320 && e.dst.cp % 4 == 0 && e.dst.bstride % 4 == 0 && ((uintptr_t)e.dst.data % 16) == 0 && ((uintptr_t)e.nrm_yhat % 16) == 0,
+                    "ROW_NORM: rows of dst and yhat must be 16-byte aligned (cp %d)", e.dst.cp);
+        d.fastw = 0;
+        return 0;
+    }
     C1V_REQUIRE(e.row_mode != C1V_ROW_UNPOOL || e.sel != nullptr, "UNPOOL needs sel");
     C1V_REQUIRE(e.reshape_w <= 0 || (e.row_mode == C1V_ROW_STORE || e.row_mode == C1V_ROW_UNPOOL), "reshape_w only with STORE/UNPOOL");
     C1V_REQUIRE(e.bias_row_w == 0 || (e.reshape_w > 0 && e.bias_row_w > 0 && e.bias_row_w <= e.reshape_w), "bias_row_w %d needs reshape_w >= it", e.bias_row_w);

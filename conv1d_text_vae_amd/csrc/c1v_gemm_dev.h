@@ -724,7 +724,11 @@ __device__ __forceinline__ void nt_body(const NtParams& p, const int bx, const i
 //   NtwTwo  128 x 128 tile, waves 2 x 2 (64 x 64 each), two-stage weight ring, <= 168 registers and 66 KiB of LDS: TWO
 //           workgroups per CU that hide each other's epilogue and ring latency, like nt_body's large variant, but with a
 //           third less to take in per K tile.
-template <int BM_, int BN_, int WGM_, int WGN_, int NSW_, bool LOOK_>
+//   NtwRow  128 x 320 tile, waves 2 x 2 (64 x 160 each), three-stage weight ring, one workgroup per CU: the WHOLE output row of
+//           a convolution with <= 320 channels (the output convolution: 302 word-vector components) lies in one workgroup,
+//           whose epilogue (C1V_ROW_NORM) then also l2-normalises it -- the loss's first step without a pass of its own over
+//           the fp32 rows.  The tile is parked in LDS in two halves of 64 rows (128 x 324 floats do not fit).
+template <int BM_, int BN_, int WGM_, int WGN_, int NSW_, bool LOOK_, int PARK_ = BM_>
 struct NtwCfg {
     static constexpr int BM = BM_, BN = BN_, WGM = WGM_, WGN = WGN_, NSW = NSW_, NSA = 2;
     static constexpr bool LOOK = LOOK_;
@@ -733,13 +737,17 @@ struct NtwCfg {
     static constexpr int A_STAGE = AROWS * 128, W_STAGE = BN * 128;
     static constexpr int RING = NSA * A_STAGE + NSW * W_STAGE;
     static constexpr int LDC = BN + 4;
-    static constexpr int LDS = RING > BM * LDC * 4 ? RING : BM * LDC * 4;
+    static constexpr int PARK = PARK_;
+    static constexpr int TAB = BN_ > 256 ? 2 * BM_ * 4 : 0;       // C1V_ROW_NORM: row sums behind the operand ring
+    static constexpr int LDS = (RING > PARK_ * LDC * 4 ? RING : PARK_ * LDC * 4) + TAB;
     static constexpr int IPA = AROWS / 8, IPW = BN / 8;
     static_assert(WGM * WGN == 4 && MI <= NJ && NJ % 2 == 0 && AROWS % 8 == 0, "wave grid");
     static_assert(IPA <= 63 && (NSW - 2) * IPW <= 63 && LDS <= 160 * 1024, "vmcnt is a 6-bit counter; LDS of a CU");
 };
 using NtwBig = NtwCfg<256, 128, 4, 1, 5, true>;
 using NtwTwo = NtwCfg<128, 128, 2, 2, 2, false>;
+using NtwRow = NtwCfg<128, 320, 2, 2, 3, false, 64>;
+using NtwRowS = NtwCfg<64, 320, 2, 2, 3, false, 64>;      // small launches: twice the workgroups, each stores half as much
 
 template <typename T, int MODE, typename Cfg>
 __device__ __forceinline__ void ntw_body(const NtParams& p, const int bx, const int by) {
@@ -831,6 +839,7 @@ __device__ __forceinline__ void ntw_body(const NtParams& p, const int bx, const 
         }
         block_barrier();                                   // the two barriers of the epilogue below
         block_barrier();
+        if constexpr (MODE == C1V_ROW_NORM && Cfg::PARK < BM) { block_barrier(); block_barrier(); }      // (two per parked part there)
         return;
     }
 
@@ -842,7 +851,31 @@ __device__ __forceinline__ void ntw_body(const NtParams& p, const int bx, const 
 
     // bias of this thread's epilogue channel group (see epilogue_rows): requested now, consumed after the K loop
     float bias4[4] = {0.f, 0.f, 0.f, 0.f};
-    {
+    // ROW_NORM: the bias of this lane's accumulator columns (wn * BN/WGN + 16 j + (lane & 15); 0 past N)
+    float biasj[NJ];
+    constexpr int NP = BM / Cfg::PARK;                     // the tile is parked in NP parts of PARK rows
+    int nrm_pos_[NP], nrm_b_[NP], nrm_u_[NP];
+    if constexpr (MODE == C1V_ROW_NORM) {
+        const int wn_ = (wave - (wave / Cfg::WGN) * Cfg::WGN) * (BN / Cfg::WGN);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int c = wn_ + 16 * j + (lane & 15);
+            biasj[j] = (ev.bias && c < ev.N) ? ev.bias[c] : 0.0f;
+        }
+        // lane l < 16 looks after rows wave + 4 l of every part: (sample, step) and the row's compact position (-2: not
+        // a row of the convolution, -1: a row without a target), requested now and used after the K loop
+#pragma unroll
+        for (int h = 0; h < NP; ++h) {
+            const int r = h * Cfg::PARK + wave + 4 * (lane & 15);
+            nrm_pos_[h] = -2;
+            rowdiv(rd, r, nrm_b_[h], nrm_u_[h]);
+            if (m0 + r < ev.M && nrm_u_[h] < ev.nrows && nrm_u_[h] < ev.dst_len) {
+                const int ridx = nrm_b_[h] * ev.nrows + nrm_u_[h];
+                const int q = ev.nrm_pos ? ev.nrm_pos[ridx] : ridx;
+                nrm_pos_[h] = q < 0 ? -1 : q;
+            }
+        }
+    } else {
         const int nbias = n0 + 4 * (tid % (BN / 4));
         if (ev.bias && ev.bias_row_w > 0) {
             const int tb = nbias / ev.reshape_w, cb = nbias - tb * ev.reshape_w;
@@ -918,6 +951,116 @@ __device__ __forceinline__ void ntw_body(const NtParams& p, const int bx, const 
     // ---- epilogue through LDS (see nt_body): the tile parked as fp32, walked by rows
     NT_T(2);
     float* ct = (float*)smem;
+    if constexpr (MODE == C1V_ROW_NORM) {
+        // 1. v = acc + bias (0 in the columns past N); sum of squares of every row from the registers: a lane squares its NJ
+        //    columns of a row, four DPP steps add the 16 lanes that share the row, the two column halves meet in LDS (behind
+        //    the operand ring: written before the barrier that ends the K loop)
+        // 2. the tile is parked in LDS in parts of PARK rows; wave w of the four walks rows w, w + 4, ... of the part, a lane
+        //    holds columns 4 lane .. 4 lane + 3 (and 256 + 4 lane ..): 16-byte stores of the fp32 row, 8-byte (bf16) stores of
+        //    the normalised row.  The walk is bound by what a CU can store (measured 15-25 B/clk: 119 KB per 64 rows), not
+        //    by its instructions: dealing 16-byte chunks across rows (29 full store instructions instead of 64) was slower.
+        constexpr int HR = Cfg::PARK, RPW = HR / 4;
+        static_assert(Cfg::WGM == 2 && Cfg::WGN == 2 && (NP == 1 || NP == 2) && BN > 256 && BN <= 512 && RPW == 16 && Cfg::TAB >= 2 * BM * 4, "row walk");
+        T* const yhat = (T*)ev.nrm_yhat;
+        float* const ydst = (float*)ev.dst;
+        float* const ssum = (float*)(smem + Cfg::LDS - Cfg::TAB);      // [2][BM]
+        {
+            const int c0 = wn * (BN / Cfg::WGN) + (lane & 15);
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                float sq[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const bool in = c0 + 16 * j < ev.N;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float v = in ? acc[i][j][r] + biasj[j] : 0.0f;
+                        acc[i][j][r] = v;
+                        sq[r] += v * v;
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = sq[r];
+                    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+                    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+                    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));   // row_half_mirror
+                    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));   // row_mirror
+                    sq[r] = v;
+                }
+                if ((lane & 15) == 0)
+                    *(float4*)(ssum + wn * BM + wm * (BM / 2) + i * 16 + (lane >> 4) * 4) = make_float4(sq[0], sq[1], sq[2], sq[3]);
+            }
+        }
+        block_barrier();                                   // operand stages are done with; the row sums are complete
+        NT_T(4);
+        const bool tail = lane < (BN - 256) / 4;
+#pragma unroll 1
+        for (int part = 0; part < NP; ++part) {
+            if (part) { NT_T(5); block_barrier(); }        // the rows of the part before are done with
+            if (NP == 1 || wm == part) {
+                // (NP == 1: waves wm = 0 / 1 hold rows 0.. / BM/2.. of the one part)
+                const int r0 = NP == 1 ? wm * (BM / 2) : 0;
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            ct[(r0 + i * 16 + (lane >> 4) * 4 + r) * Cfg::LDC + wn * (BN / Cfg::WGN) + j * 16 + (lane & 15)] = acc[i][j][r];
+            }
+            const int my_b = part ? nrm_b_[NP - 1] : nrm_b_[0], my_u = part ? nrm_u_[NP - 1] : nrm_u_[0];
+            const int my_pos = part ? nrm_pos_[NP - 1] : nrm_pos_[0];
+            float my_rr;
+            {
+                const int r = part * HR + wave + 4 * (lane & (RPW - 1));
+                my_rr = 1.0f / sqrtf(fmaxf(ssum[r] + ssum[BM + r], 1e-12f));
+                if (lane < RPW && my_pos >= 0) ev.nrm_rnorm[my_b * ev.nrows + my_u] = my_rr;
+            }
+            const int64_t my_y = (int64_t)my_b * ev.dst_bstride + (int64_t)(ev.dst_off + my_u) * ev.dst_cp;
+            block_barrier();
+            // rows in groups of four: the LDS reads of a group are issued together, then its stores
+#pragma unroll
+            for (int l0 = 0; l0 < RPW; l0 += 4) {
+                float4 va[4], vb[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float* cr = ct + (wave + 4 * (l0 + k)) * Cfg::LDC + 4 * lane;
+                    va[k] = *(const float4*)cr;
+                    vb[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (tail) vb[k] = *(const float4*)(cr + 256);
+                }
+#pragma unroll
+                for (int k4 = 0; k4 < 4; ++k4) {
+                    const int l = l0 + k4;
+                    const int pos = __builtin_amdgcn_readlane(my_pos, l);
+                    const float sc = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_rr), l)) * ev.nrm_qscale;
+                    const int64_t yo = ((int64_t)__builtin_amdgcn_readlane((int)(my_y >> 32), l) << 32) |
+                                       (uint32_t)__builtin_amdgcn_readlane((int)my_y, l);
+                    const float4 a4 = va[k4], b4 = vb[k4];
+                    // (pos == -2: not a row of the convolution -- between samples / past the end)
+                    if (pos >= 0 || (pos == -1 && !ev.nrm_live_only)) {
+                        float* yr = ydst + yo + 4 * lane;
+                        if (4 * lane < ev.dst_cp) *(float4*)yr = a4;
+                        if (tail && 256 + 4 * lane < ev.dst_cp) *(float4*)(yr + 256) = b4;
+                    }
+                    if (pos >= 0) {
+                        const int64_t ho = (int64_t)pos * ev.nrm_kp + 4 * lane;
+                        if constexpr (sizeof(T) == 2) {
+                            if (4 * lane < ev.nrm_kp)
+                                *(uint2*)((bf16_raw*)yhat + ho) = make_uint2(pack_bf16x2(a4.x * sc, a4.y * sc), pack_bf16x2(a4.z * sc, a4.w * sc));
+                            if (tail && 256 + 4 * lane < ev.nrm_kp)
+                                *(uint2*)((bf16_raw*)yhat + ho + 256) = make_uint2(pack_bf16x2(b4.x * sc, b4.y * sc), pack_bf16x2(b4.z * sc, b4.w * sc));
+                        } else {
+                            if (4 * lane < ev.nrm_kp) *(float4*)((float*)yhat + ho) = make_float4(a4.x * sc, a4.y * sc, a4.z * sc, a4.w * sc);
+                            if (tail && 256 + 4 * lane < ev.nrm_kp)
+                                *(float4*)((float*)yhat + ho + 256) = make_float4(b4.x * sc, b4.y * sc, b4.z * sc, b4.w * sc);
+                        }
+                    }
+                }
+            }
+        }
+    } else {
     block_barrier();                                       // every wave is done reading the last operand stages
     NT_T(4);
 #pragma unroll
@@ -932,6 +1075,7 @@ __device__ __forceinline__ void ntw_body(const NtParams& p, const int bx, const 
     // (one row mode per instantiation, 4-wide vector epilogue only -- the host takes this variant for such launches only: with
     // every mode in one kernel the epilogue was 26 k instructions of straight-line code and ~3 k SGPR spill moves)
     epi_seq_rows<BM, BN, MODE, 4>(ev, rd, ct, Cfg::LDC, m0, n0, tid, bias4);
+    }
 #ifdef NT_STAMP
     NT_T(6);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

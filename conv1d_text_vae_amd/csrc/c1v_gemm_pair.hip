@@ -122,7 +122,7 @@ template <typename T> static int launch_pair_t(PairParams& pp, hipStream_t st) {
 int c1v_launch_pair(int dtype, const NtParams& nt, const TnParams& tn, hipStream_t st) {
     if (c1v_check_nt(nt) || c1v_check_tn(tn)) return -1;
     C1V_REQUIRE(nt.ksplits <= 1, "pair launch: split-K dgrad is not supported");
-    if (nt.wide == 2 || tn.tg >= 2) {
+    if (nt.wide >= 2 || tn.tg >= 2) {
         // the large-batch variants (one workgroup per CU each: 256 x 128 dgrad tiles, fused-tap wgrad) fill the chip by
         // themselves: two launches, wgrad first
         if (c1v_launch_tn(dtype, tn, st)) return -1;

@@ -573,10 +573,18 @@ class VAEEngine:
                 if bn:
                     ops += self._bn_fwd_ops('deconv_decoder_batchnorm_%d' % (i + 1), self.Ad[i], L.BN_UP2,
                                             dstb.seq(length=dst_len), train)
-            e = self._epi(self.Y.seq(), L.ROW_STORE, self._bias_ptr('deconv_decoder_embeddings/bias'))
-            ops.append(op('c1v_conv1d_fwd', L.ConvArgs(self.Xf.seq(), 0, g.output_text_size, k,
-                                                       self.wop['out_fwd'].data_ptr(), self.wld['out_fwd'], self.V, e)))
             return ops
+
+        def out_conv(norm: bool, live_only: bool):
+            """The output convolution (a7).  norm: its epilogue also l2-normalises the rows into the loss kernel's operand
+            (C1V_ROW_NORM: one workgroup holds a whole row) -- no c1v_l2norm_rows launch, no second pass over the fp32 rows."""
+            e = self._epi(self.Y.seq(), L.ROW_NORM if norm else L.ROW_STORE, self._bias_ptr('deconv_decoder_embeddings/bias'))
+            if norm:
+                e.nrm_yhat, e.nrm_kp, e.nrm_rnorm, e.nrm_qscale = self.yhat.data_ptr(), self.kp, self.rnorm.data_ptr(), self.qscale
+                e.nrm_pos = self.row_pos.data_ptr() if self.compact else None
+                e.nrm_live_only = 1 if (live_only and self.compact) else 0
+            return op('c1v_conv1d_fwd', L.ConvArgs(self.Xf.seq(), 0, g.output_text_size, k,
+                                                   self.wop['out_fwd'].data_ptr(), self.wld['out_fwd'], self.V, e))
 
         self.ops_gather_in = None          # built by set_input_table (device-side batch assembly)
         if getattr(self, 'in_table', None) is not None:
@@ -586,8 +594,22 @@ class VAEEngine:
         self.ops_lat_train = [op('c1v_latent_head_fwd', self._lat_train)]
         self.ops_lat_eval = [op('c1v_latent_head_fwd', self._lat_eval)]
         self.ops_lat_infer = [op('c1v_latent_head_fwd', self._lat_infer)]
-        self.ops_dec_train = dec_fwd(True)
-        self.ops_dec_infer = dec_fwd(False) if bn else self.ops_dec_train
+        # whole-row output convolution with the normalisation in its epilogue: rows of <= 320 padded columns, input channels in
+        # whole 128-byte strips (C1V_FUSE_NORM=0: STORE + c1v_l2norm_rows, the round-2 sequence; results are bit-identical)
+        # Not for a long reduction over few rows (the demo model: 2048 input channels = 96 K tiles, 52 row tiles): the
+        # whole-row kernel then keeps a fifth of the CUs busy where the 64 x 64 tiles of the plain kernel fill the chip
+        # (measured 57 us against 40 + 5 us); C1V_FUSE_NORM=1 forces it wherever it applies.
+        es = 2 if self.code == L.BF16 else 4
+        env_fn = os.environ.get('C1V_FUSE_NORM', 'auto')
+        k_tiles = k * ((self.Xf.cp * es) // 128)
+        row_tiles = -(-(B * self.Xf.pitch) // 64)
+        self.fuse_norm = (self.N > 0 and self.kp <= 320 and (self.Xf.cp * es) % 128 == 0 and 2 <= k <= 9 and env_fn != '0' and
+                          (env_fn == '1' or k_tiles <= 12 or row_tiles >= 192))
+        body_train = dec_fwd(True)
+        body_infer = dec_fwd(False) if bn else body_train
+        self.ops_dec_train = body_train + [out_conv(self.fuse_norm, os.environ.get('C1V_NORM_LIVE_ONLY', '1') != '0')]
+        self.ops_dec_infer = body_infer + [out_conv(False, False)]
+        self.ops_dec_eval = body_infer + [out_conv(True, False)] if self.fuse_norm else self.ops_dec_infer
         self.ops_dec = self.ops_dec_train
         self.ops_post = []
         f_eos = self.lib.c1v_eos_truncate_normalize_ld
@@ -597,6 +619,7 @@ class VAEEngine:
                           self.end_idx.data_ptr(), self._stream()), 'c1v_eos_truncate_normalize_ld')
         self.ops_post = [run_post]
         self._ops_built = True
+        self.ops_live_first = []
         if self.N == 0:
             return
 
@@ -613,8 +636,9 @@ class VAEEngine:
                                          self.max_splits, self.row_pos.data_ptr(), self.live_ctl.data_ptr())
 
         def loss_ops(train: bool):
-            ops = [op('c1v_l2norm_rows', L.L2NormArgs(self.Y.t.data_ptr(), self.M, self.V, self.Vp, self.yhat.data_ptr(),
-                                                      self.code, self.kp, self.rnorm.data_ptr(), self.qscale, pos_ptr))]
+            ops = [] if self.fuse_norm else [
+                op('c1v_l2norm_rows', L.L2NormArgs(self.Y.t.data_ptr(), self.M, self.V, self.Vp, self.yhat.data_ptr(),
+                                                   self.code, self.kp, self.rnorm.data_ptr(), self.qscale, pos_ptr))]
             ops.append(op('c1v_cos_softmax_accum', L.XentAccumArgs(
                 self.yhat.data_ptr(), self.code, self.M, self.kp, self.w_vocab.data_ptr(), self.N, self.n_pad,
                 self.ut.data_ptr(), self.m_pad, self.x_splits, 1 if train else 0, self.ones_col,
@@ -627,7 +651,8 @@ class VAEEngine:
                 self.dOf.seq() if train else _null_seq(), self.Y.t.data_ptr(), self.Vp, pos_ptr, ctl_ptr,
                 self.ut_code if train else L.F32)))
             core = list(ops)
-            ops = self.ops_live_rows + ops
+            if not self.fuse_norm:                         # (fused: the output convolution already needs the positions)
+                ops = self.ops_live_rows + ops
             f_red = self.lib.c1v_loss_reduce
 
             def red():
@@ -637,10 +662,10 @@ class VAEEngine:
             return ops, red, core
 
         self.ops_loss_train, self.op_loss_reduce, self.ops_loss_train_core = loss_ops(True)
-        n0 = len(self.ops_live_rows)
-        self.op_xent_accum, self.op_xent_finish = self.ops_loss_train[n0 + 1], self.ops_loss_train[n0 + 2]   # benchmarks
-        self.ops_loss_eval, red_eval, _ = loss_ops(False)
-        self.op_xent_accum_eval = self.ops_loss_eval[n0 + 1]
+        self.ops_live_first = self.ops_live_rows if self.fuse_norm else []
+        self.op_xent_accum, self.op_xent_finish = self.ops_loss_train_core[-2], self.ops_loss_train_core[-1]   # benchmarks
+        self.ops_loss_eval, red_eval, core_eval = loss_ops(False)
+        self.op_xent_accum_eval = core_eval[-2]
         self.ops_loss_eval = self.ops_loss_eval + [red_eval]
 
         # ---- backward
@@ -1121,8 +1146,8 @@ class VAEEngine:
                 own_in = self.ops_live_rows + self._in_ops(from_ids)
             return [self._prologue_op(with_rng, from_ids, advance)] + own_in + self.ops_enc_train + self.ops_lat_train + \
                 self.ops_dec_train + self.ops_loss_train_core
-        return (self.ops_rng if with_rng else []) + self._in_ops(from_ids) + self.ops_enc_train + self.ops_lat_train + \
-            self.ops_dec_train + self.ops_loss_train
+        return (self.ops_rng if with_rng else []) + self.ops_live_first + self._in_ops(from_ids) + self.ops_enc_train + \
+            self.ops_lat_train + self.ops_dec_train + self.ops_loss_train
 
     def train_ops(self, with_rng: bool, from_ids: bool = False, advance: bool = False):
         return self.forward_ops(with_rng, from_ids, advance) + [self._run_backward] + self.ops_finalize
@@ -1208,8 +1233,8 @@ class VAEEngine:
     def eval_step(self, use_graph: bool = True, fixed_rng: bool = False, from_ids: bool = False):
         """Validation loss of the resident batch (dropout off, eps still sampled -- Keras test phase of FullVAE)."""
         self._ensure_packed()
-        ops = ([] if fixed_rng else self.ops_rng_eval) + self._in_ops(from_ids) + self.ops_enc_infer + self.ops_lat_eval + \
-            self.ops_dec_infer + self.ops_loss_eval
+        ops = ([] if fixed_rng else self.ops_rng_eval) + self.ops_live_first + self._in_ops(from_ids) + self.ops_enc_infer + \
+            self.ops_lat_eval + self.ops_dec_eval + self.ops_loss_eval
         if use_graph:
             self._graph(('eval_fixed' if fixed_rng else 'eval') + ('@ids' if from_ids else ''), ops)
         else:

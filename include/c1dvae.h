@@ -55,6 +55,13 @@ typedef struct c1v_seq {
                                 d loss / d zd; the epilogue applies c1v_latent_head_bwd's arithmetic (dropout mask, sampling
                                 and KL terms, see the lat_* fields) and stores dst(b, d) and dst(b, lat_D + d).  Vector
                                 epilogue only (lat_D a multiple of 4, 16-byte aligned buffers). */
+#define C1V_ROW_NORM    6   /* STORE + the first step of the loss in the same pass (a7 + a8, reference :1279-1280 + :1195): the
+                                whole output row (n_out <= 320 channels) lies in ONE workgroup, so besides dst(b, u, :) = v the
+                                epilogue writes yhat[pos][:] = v / sqrt(max(sum v^2, 1e-12)) * nrm_qscale (compute dtype, zero
+                                padded to nrm_kp) and rnorm[row] -- what c1v_l2norm_rows would compute from dst in a launch of its
+                                own.  row = b * n_rows + u; pos = nrm_pos ? nrm_pos[row] : row, rows with pos < 0 get no yhat
+                                (and, with nrm_live_only, no dst row either: a training step never reads them).  Convolutions
+                                over whole 128-byte channel strips only (c1v_conv1d_fwd checks). */
 
 /* Generic fused epilogue applied by conv / dense kernels to each accumulator element (u, n) of sample b:
  *   v += bias[n]; v = relu(v) if relu;
@@ -84,6 +91,8 @@ typedef struct c1v_epilogue {
     int32_t        bias_row_w;  /* with reshape_w: the GEMM was laid out with every (t, .) row padded from bias_row_w up to
                                    reshape_w channels (zero weight rows) so that the vector epilogue applies to widths that
                                    are not multiples of 4; bias index = t*bias_row_w + c, pad channels get 0.  0 = no padding */
+    /* C1V_ROW_NORM only (see above; the arguments of c1v_l2norm_args) */
+    void*          nrm_yhat; int32_t nrm_kp; float* nrm_rnorm; float nrm_qscale; const int32_t* nrm_pos; int32_t nrm_live_only;
 } c1v_epilogue;
 
 /* ---- a1 / a6 / a7: Conv1D('valid'|'same') and Conv2DTranspose((k,1)) forward (:1227-1280) -------------

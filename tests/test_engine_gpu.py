@@ -245,6 +245,51 @@ def test_wide_window_nt_variant_is_bit_identical(name, dtype, monkeypatch):
             np.testing.assert_array_equal(got[mode][0][k_], v, err_msg=k_)
 
 
+@pytest.mark.parametrize('name', ['deep3', 'k4', 'k2', 'mid', 'wide', 'big128'])
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_output_convolution_with_fused_l2norm(name, dtype, monkeypatch):
+    """C1V_ROW_NORM (the output convolution's workgroup holds whole rows and l2-normalises them in its epilogue: yhat at the
+    compact live-row position, rnorm, fp32 y of the live rows) against STORE + c1v_l2norm_rows.  The fp32 rows of y must
+    agree to the bit.  The sum of squares of a row is added up in another order (accumulator registers + DPP instead of a
+    pass over the stored row), so 1 / |y| may differ in its last bits: the normalised operand within one rounding step of
+    its type, loss and gradients within 1e-6 (f32) / 2e-3 (bf16: single flipped roundings of yhat), and the same for the
+    validation loss (eval_step: the same epilogue over ALL rows of y)."""
+    c = CASES[name]
+    og, params, Wv, x, ids, eps, mask_e, mask_d = make_case(c)
+    got = {}
+    monkeypatch.setenv('C1V_NORM_LIVE_ONLY', '1')         # the product default (conftest.py turns it off for the other tests)
+    for mode in ('1', '0'):
+        monkeypatch.setenv('C1V_FUSE_NORM', mode)
+        eng = build_engine(c, og, params, Wv, dtype)
+        if mode == '1' and not eng.fuse_norm:
+            pytest.skip('this shape does not take the whole-row kernel (%d-byte channel rows)' % (eng.Xf.cp * (2 if dtype == 'bf16' else 4)))
+        assert eng.fuse_norm == (mode == '1')
+        load_fixed(eng, x, ids, eps, mask_e, mask_d)
+        eng._run(eng.train_ops(False))
+        torch.cuda.synchronize()
+        live = (ids.reshape(-1) >= 0) if eng.compact else np.ones(ids.size, bool)
+        y = eng.y_pred().cpu().numpy().reshape(ids.size, -1)[live]
+        n_rows = int(live.sum()) if eng.compact else ids.size
+        yhat = eng.yhat[:n_rows * eng.kp].float().cpu().numpy().reshape(n_rows, eng.kp)
+        rn = eng.rnorm[:ids.size].cpu().numpy()[live]
+        res = [eng.get_grads(), eng.loss(), y, yhat, rn]
+        eng.eval_step(use_graph=False, fixed_rng=True)
+        torch.cuda.synchronize()
+        res += [eng.loss(), eng.y_pred().cpu().numpy()]
+        got[mode] = res
+    a, b = got['1'], got['0']
+    np.testing.assert_array_equal(a[2], b[2])
+    np.testing.assert_array_equal(a[6], b[6])
+    np.testing.assert_allclose(a[4], b[4], rtol=1e-6, atol=0)
+    step = 2.0 ** -7 if dtype == 'bf16' else 4e-7
+    assert np.all(np.abs(a[3] - b[3]) <= step * np.abs(b[3]) + 1e-30)
+    assert np.all(a[3][:, eng.V:] == 0)
+    tol = 2e-3 if dtype == 'bf16' else 1e-6
+    assert abs(a[1] - b[1]) <= tol * abs(b[1]) and abs(a[5] - b[5]) <= tol * abs(b[5])
+    for k_, v in b[0].items():
+        assert rel_l2(a[0][k_], v) < tol, (k_, rel_l2(a[0][k_], v))
+
+
 @pytest.mark.parametrize('dtype', ['f32', 'bf16'])
 def test_step_prologue_and_live_rows_are_bit_identical(dtype, monkeypatch):
     """One-launch step prologue (rng + input pack + live-row table) and the compacted loss rows against the separate
