@@ -59,6 +59,11 @@ class FastTextKeyedVectors:
         self.vectors = np.zeros((0, self.vector_size), dtype=np.float32)
         self.vectors_ngrams = np.zeros((self.bucket, self.vector_size), dtype=np.float32)
         self._topn = None                                   # lazily built device index (engine.VocabTopN)
+        # Opt-in, for tables too large for one GPU or a decode spread over the ranks of a torchrun job: every rank keeps
+        # rows [begin, end) of the table on its GPU and `similar_by_vectors` becomes a COLLECTIVE (dist.ShardedVocabTopN:
+        # every rank must call it with the same queries; per-shard lists are all-gathered and merged).  Off by default --
+        # a single process, or ranks that decode different queries, need the whole table each.
+        self.shard_over_ranks = False
 
     # ---- construction ----------------------------------------------------------------------------------
     def add(self, words: Sequence[str], vectors: np.ndarray):
@@ -124,7 +129,11 @@ class FastTextKeyedVectors:
         norms[norms == 0.0] = 1.0
         topn = int(min(topn, len(self.index2word)))
         if self._topn is None or self._topn.device_str != device:
-            self._topn = VocabTopN(self.vectors_norm, device=device)
+            if self.shard_over_ranks:
+                from .dist import ShardedVocabTopN
+                self._topn = ShardedVocabTopN(self.vectors_norm, device=device)
+            else:
+                self._topn = VocabTopN(self.vectors_norm, device=device)
         score, idx = self._topn.run(q / norms, topn)
         return [[(self.index2word[int(idx[m, j])], float(score[m, j])) for j in range(topn)] for m in range(q.shape[0])]
 
@@ -148,6 +157,10 @@ class FastTextKeyedVectors:
         st = dict(self.__dict__)
         st['_topn'] = None                                  # device index is rebuilt on demand
         return st
+
+    def __setstate__(self, st):
+        self.__dict__.update(st)
+        self.__dict__.setdefault('shard_over_ranks', False)
 
 
 KEYED_VECTOR_TYPES = (FastTextKeyedVectors,) if _GensimFastTextKeyedVectors is None else \

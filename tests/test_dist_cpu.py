@@ -266,3 +266,38 @@ def test_sharded_topn_matches_unsharded():
         ret = m.dict()
         mp.spawn(_topn_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
         assert all(ret[r] for r in range(world))
+
+
+def _kv_worker(rank, world, port, ret):
+    from conv1d_text_vae_amd.dist import ShardedVocabTopN
+    from conv1d_text_vae_amd.embeddings import FastTextKeyedVectors
+    _init(rank, world, port)
+    rng = np.random.RandomState(1)
+    kv = FastTextKeyedVectors(8, 3, 5)
+    words = ['w%02d' % i for i in range(33)]
+    kv.add(words, rng.randn(33, 8).astype(np.float32))
+    Wn = kv.vectors_norm
+    b, e = shard_range(Wn.shape[0], world, rank)
+
+    def local_fn(queries, topn):            # (the rank's rows ranked on the CPU: the HIP VocabTopN needs a GPU)
+        s = queries @ Wn[b:e].T
+        order = np.lexsort((np.broadcast_to(np.arange(e - b), s.shape), -s), axis=1)[:, :topn]
+        return np.take_along_axis(s, order, axis=1), (order + b).astype(np.int32)
+    kv.shard_over_ranks = True
+    kv._topn = ShardedVocabTopN(Wn, device='cpu', local_fn=local_fn)
+    q = rng.randn(5, 8).astype(np.float32)
+    got = kv.similar_by_vectors(q, topn=4, device='cpu')
+    s = (q / np.linalg.norm(q, axis=1, keepdims=True)) @ Wn.T
+    ref = np.argsort(-s, axis=1, kind='stable')[:, :4]
+    ret[rank] = [[w for w, _ in row] for row in got] == [[words[j] for j in row] for row in ref]
+    dist.destroy_process_group()
+
+
+def test_keyed_vectors_similar_by_vectors_over_a_sharded_table():
+    """FastTextKeyedVectors.shard_over_ranks: `similar_by_vectors` (find_best_words' search, reference :584-587) as a
+    collective over two ranks, each ranking half of the table, returns the words of the unsharded ranking on every rank."""
+    world = 2
+    with mp.Manager() as m:
+        ret = m.dict()
+        mp.spawn(_kv_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+        assert all(ret[r] for r in range(world))
