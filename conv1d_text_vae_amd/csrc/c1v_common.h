@@ -89,6 +89,19 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// The same sum through DPP row operations and four lane reads instead of six LDS-crossbar permutes (each of those is an LDS
+// round trip; a wave that is alone on its dependency chain waits for every one).  Another order of the additions than
+// wave_sum: not interchangeable where results are compared to the bit.
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));   // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));   // row_mirror
+    const int i = __builtin_bit_cast(int, v);
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 0)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 16)) +
+           __builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 48));
+}
+
 // ---- host side -------------------------------------------------------------------------------------
 void c1v_set_error(const char* fmt, ...);
 #define C1V_REQUIRE(cond, ...) do { if (!(cond)) { c1v_set_error(__VA_ARGS__); return -1; } } while (0)

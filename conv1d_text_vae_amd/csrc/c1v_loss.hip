@@ -609,13 +609,13 @@ template <bool UB> __device__ __forceinline__ float ut_f(const float* ut, int64_
     if constexpr (UB) return __uint_as_float((uint32_t)((const bf16_raw*)ut)[i] << 16);
     else return ut[i];
 }
+#define C1V_FINISH_PARAMS const float* __restrict__ ut, int splits, int kp, int m_pad, int ones_col, const T* __restrict__ yhat, \
+    const T* __restrict__ w, const float* __restrict__ rnorm, float qscale, const int* __restrict__ ids, int B, int T_len, int V, \
+    int B_global, float* __restrict__ xent_rows, c1v_seq dy, const float* __restrict__ y, int64_t ldy, const int* __restrict__ pos, \
+    const int* __restrict__ ctl
+#define C1V_FINISH_ARGS ut, splits, kp, m_pad, ones_col, yhat, w, rnorm, qscale, ids, B, T_len, V, B_global, xent_rows, dy, y, ldy, pos, ctl
 template <typename T, bool UB>
-__global__ __launch_bounds__(256) void xent_finish_kernel(const float* __restrict__ ut, int splits, int kp, int m_pad, int ones_col,
-                                                          const T* __restrict__ yhat, const T* __restrict__ w,
-                                                          const float* __restrict__ rnorm, float qscale,
-                                                          const int* __restrict__ ids, int B, int T_len, int V, int B_global,
-                                                          float* __restrict__ xent_rows, c1v_seq dy, const float* __restrict__ y, int64_t ldy,
-                                                          const int* __restrict__ pos, const int* __restrict__ ctl) {
+__device__ __forceinline__ void xent_finish_body(C1V_FINISH_PARAMS) {
     // one wave per sample row; everything is row-wise and coalesced.  The projection that backpropagates through the
     // l2-normalisation uses yhat = y * rnorm in fp32 when `y` is given: a bf16-rounded yhat leaves a residue ALONG y,
     // which the transposed final conv amplifies coherently (measured: 6x larger relative error downstream).
@@ -779,8 +779,8 @@ __global__ __launch_bounds__(256) void xent_finish_kernel(const float* __restric
 #pragma unroll
             for (int e = 0; e < 4; ++e)
                 if (4 * (lane + 64 * q) + e < V) st1 += yh[q][e] * wv[q][e];
-        cnt1 = wave_sum(cnt1);
-        st1 = wave_sum(st1);
+        cnt1 = wave_sum_dpp(cnt1);
+        st1 = wave_sum_dpp(st1);
         const float p1 = exp2f(st1) / se;
         const bool live1 = p1 > 1e-7f && p1 < (1.0f - 1e-7f);
         if (lane == 0) xent_rows[m] = -logf(fminf(fmaxf(p1, 1e-7f), 1.0f - 1e-7f));
@@ -798,7 +798,7 @@ __global__ __launch_bounds__(256) void xent_finish_kernel(const float* __restric
                 yv[q][e] = in ? (y ? yv[q][e] * rn1 : yh[q][e] * inv_q) : 0.f;
                 dot1 += us[q][e] * yv[q][e];
             }
-        dot1 = wave_sum(dot1);
+        dot1 = wave_sum_dpp(dot1);
         const bool st8 = dy.dtype == C1V_BF16 && ((((uintptr_t)dy.data) & 7) == 0) && (dy.cp & 3) == 0 && (dy.bstride & 3) == 0;
 #pragma unroll
         for (int q = 0; q < NCH; ++q) {
@@ -825,8 +825,8 @@ __global__ __launch_bounds__(256) void xent_finish_kernel(const float* __restric
     if (mask)
         for (int c = lane; c < V; c += 64)
             st += ElemTraits<T>::load(yhat, (int64_t)cr * kp + c) * ElemTraits<T>::load(w, (int64_t)id * kp + c);
-    cnt = wave_sum(cnt);
-    st = wave_sum(st);
+    cnt = wave_sum_dpp(cnt);
+    st = wave_sum_dpp(st);
     const float p_t = exp2f(st) / sumexp;
     const bool live = mask && p_t > 1e-7f && p_t < (1.0f - 1e-7f);
     const float p_c = fminf(fmaxf(p_t, 1e-7f), 1.0f - 1e-7f);
@@ -870,7 +870,7 @@ __global__ __launch_bounds__(256) void xent_finish_kernel(const float* __restric
                 dot += uu[k] * yy[k];
             }
         }
-        dot = wave_sum(dot);
+        dot = wave_sum_dpp(dot);
 #pragma unroll
         for (int k = 0; k < UC; ++k) {
             const int c = lane + 64 * k;
@@ -884,7 +884,7 @@ __global__ __launch_bounds__(256) void xent_finish_kernel(const float* __restric
         const float dyh = coef * (u * inv_se - ElemTraits<T>::load(w, (int64_t)id * kp + c));
         dot += dyh * (y ? y[(int64_t)m * ldy + c] * rn : ElemTraits<T>::load(yhat, (int64_t)cr * kp + c) * inv_q);
     }
-    dot = wave_sum(dot);
+    dot = wave_sum_dpp(dot);
     for (int c = lane; c < V; c += 64) {
         float u = 0.f;
         for (int sp = 0; sp < splits; ++sp) u += ut_f<UB>(ut, ((int64_t)sp * m_pad + cr) * kp + c);
@@ -892,6 +892,18 @@ __global__ __launch_bounds__(256) void xent_finish_kernel(const float* __restric
         const float yh = y ? y[(int64_t)m * ldy + c] * rn : ElemTraits<T>::load(yhat, (int64_t)cr * kp + c) * inv_q;
         store_any(dy.data, dy.dtype, drow + c, normal ? (dyh - yh * dot) * rn : dyh * rn);
     }
+}
+template <typename T, bool UB>
+__global__ __launch_bounds__(256) void xent_finish_kernel(C1V_FINISH_PARAMS) { xent_finish_body<T, UB>(C1V_FINISH_ARGS); }
+// The training instance (bf16 operands, bf16 slabs) at EIGHT waves per SIMD: the kernel is one wave per row and two dependent
+// memory round trips long, so its time is rows / resident waves.  The compiler wanted 66 registers (7 waves); held to 64 it
+// spills three dwords -- C2's 8192 rows then fit ONE round of the chip's 8192 wave slots instead of 1.14.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8)))
+void xent_finish_bf16_kernel(const float* __restrict__ ut, int splits, int kp, int m_pad, int ones_col, const bf16_raw* __restrict__ yhat,
+                             const bf16_raw* __restrict__ w, const float* __restrict__ rnorm, float qscale, const int* __restrict__ ids, int B,
+                             int T_len, int V, int B_global, float* __restrict__ xent_rows, c1v_seq dy, const float* __restrict__ y, int64_t ldy,
+                             const int* __restrict__ pos, const int* __restrict__ ctl) {
+    xent_finish_body<bf16_raw, true>(C1V_FINISH_ARGS);
 }
 
 // loss scalars: see c1v_lossred.h
@@ -1128,7 +1140,10 @@ extern "C" int c1v_cos_softmax_finish(const c1v_xent_finish_args* a, void* strea
         a->m_pad, a->ones_col, (const ELEM*)a->yhat, (const ELEM*)a->w, a->rnorm, a->qscale, a->ids, a->B, a->T, a->V, a->B_global, a->xent_rows, a->dy, a->y, \
         a->ldy, a->pos, a->live_ctl)
     if (a->dtype == C1V_F32) C1V_FINISH(float, false);
-    else if (a->ut_dtype == C1V_BF16) C1V_FINISH(bf16_raw, true);
+    else if (a->ut_dtype == C1V_BF16)
+        hipLaunchKernelGGL(xent_finish_bf16_kernel, grid, dim3(256), lds, (hipStream_t)stream, (const float*)a->ut, a->splits, a->kp, a->m_pad,
+                           a->ones_col, (const bf16_raw*)a->yhat, (const bf16_raw*)a->w, a->rnorm, a->qscale, a->ids, a->B, a->T, a->V, a->B_global,
+                           a->xent_rows, a->dy, a->y, a->ldy, a->pos, a->live_ctl);
     else C1V_FINISH(bf16_raw, false);
 #undef C1V_FINISH
     C1V_LAUNCH_CHECK();
