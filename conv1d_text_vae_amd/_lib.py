@@ -135,6 +135,11 @@ class LossReduceArgs(C.Structure):
                 ('B_global', C.c_int32), ('out3', C.c_void_p), ('xent_b', C.c_void_p)]
 
 
+class GradFinalizeArgs(C.Structure):
+    _fields_ = [('segs', C.c_void_p), ('n_seg', C.c_int32), ('total_blocks', C.c_int32), ('grad', C.c_void_p),
+                ('sq_partial', C.c_void_p), ('loss', C.c_void_p)]
+
+
 class NadamArgs(C.Structure):
     _fields_ = [('p', C.c_void_p), ('g', C.c_void_p), ('m', C.c_void_p), ('v', C.c_void_p), ('n', C.c_int64),
                 ('grad_scale', C.c_float),
@@ -218,6 +223,7 @@ SYMBOLS = {
     'c1v_loss_reduce': ([C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
                          C.c_void_p, C.c_void_p], C.c_int),
     'c1v_grad_finalize': ([C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p], C.c_int),
+    'c1v_grad_finalize_step': ([_P(GradFinalizeArgs), C.c_void_p], C.c_int),
     'c1v_grad_finalize_loss': ([C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, _P(LossReduceArgs), C.c_void_p],
                                C.c_int),
     'c1v_sqnorm_partial': ([C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p], C.c_int),
@@ -240,6 +246,7 @@ SYMBOLS = {
     'c1v_counter_add': ([C.c_void_p, C.c_uint64, C.c_void_p], C.c_int),
     'c1v_philox_multi': ([C.c_void_p, C.c_int32, C.c_int32, C.c_uint64, C.c_void_p, C.c_void_p], C.c_int),
     'c1v_step_prologue': ([_P(StepPrologueArgs), C.c_void_p], C.c_int),
+    'c1v_run_list': ([C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p], C.c_int),
     'c1v_last_error': ([], C.c_char_p),
     'c1v_version': ([], C.c_int),
     'c1v_device_info': ([C.c_int32, _P(C.c_int32)], C.c_int),

@@ -186,3 +186,14 @@ extern "C" int c1v_bwd_pair(const c1v_bwd_pair_args* a, void* stream) {
 extern "C" int c1v_conv1d_wgrad(const c1v_wgrad_args* a, void* s) { return c1v_wgrad(a, s); }
 extern "C" int c1v_deconv1d_wgrad(const c1v_wgrad_args* a, void* s) { return c1v_wgrad(a, s); }
 extern "C" int c1v_dense_wgrad(const c1v_wgrad_args* a, void* s) { return c1v_wgrad(a, s); }
+
+// ---- recorded step --------------------------------------------------------------------------------------
+extern "C" int c1v_run_list(int32_t n, const c1v_op_fn* fns, const void* const* args, void* stream) {
+    C1V_REQUIRE(n >= 0 && (n == 0 || (fns && args)), "run_list: null argument");
+    for (int32_t i = 0; i < n; ++i) {
+        C1V_REQUIRE(fns[i] != nullptr, "run_list: entry %d has no function", i);
+        const int rc = fns[i](args[i], stream);
+        if (rc != 0) return rc;
+    }
+    return 0;
+}

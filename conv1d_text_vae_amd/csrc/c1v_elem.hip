@@ -838,3 +838,9 @@ extern "C" int c1v_counter_add(uint64_t* ctr, uint64_t inc, void* stream) {
     C1V_LAUNCH_CHECK();
     return 0;
 }
+
+extern "C" int c1v_grad_finalize_step(const c1v_grad_finalize_args* a, void* stream) {
+    C1V_REQUIRE(a, "grad_finalize_step: null argument");
+    if (a->loss) return c1v_grad_finalize_loss(a->segs, a->n_seg, a->total_blocks, a->grad, a->sq_partial, a->loss, stream);
+    return c1v_grad_finalize(a->segs, a->n_seg, a->total_blocks, a->grad, a->sq_partial, stream);
+}

@@ -103,6 +103,7 @@ class VAEEngine:
         self.std_scale = float(std_scale)
         self._keep = []        # python objects that must outlive the captured graphs
         self._graphs: Dict[str, torch.cuda.CUDAGraph] = {}
+        self._lists: Dict[str, object] = {}            # recorded op lists of c1v_run_list
         k = geom.kernel_size
         B = self.B
         nl = len(geom.n_filters)
@@ -429,6 +430,7 @@ class VAEEngine:
             rc = f(ref, self._stream())
             if rc != 0:
                 L.check(rc, fn)
+        run.c_fn, run.c_args = f, args                   # what c1v_run_list needs to issue this op natively
         return run
 
     # ---- BatchNormalization ops (use_batch_norm=True) ------------------------------------------------------------
@@ -505,6 +507,7 @@ class VAEEngine:
         nd = len(g.dec_filters)
         self._keep = []
         self._graphs = {}
+        self._lists = {}
         op = self._op
         # ---- encoder forward (train / inference differ only in the dropout mask of the last layer)
         self._pack_in_args = L.PackInputArgs(self.x_in.data_ptr(), g.input_text_size, g.input_vector_size, self.Xe[0].seq())
@@ -903,14 +906,10 @@ class VAEEngine:
             descs, n, blocks = table
             self._keep.append(descs)
 
-            def fin():
-                sq = self.sq_partial.data_ptr() if with_sq else None
-                if with_loss:
-                    L.check(f_fin_loss(descs.data_ptr(), n, blocks, self.grads.data_ptr(), sq, C.byref(loss_args),
-                                       self._stream()), 'c1v_grad_finalize_loss')
-                else:
-                    L.check(f_fin(descs.data_ptr(), n, blocks, self.grads.data_ptr(), sq, self._stream()), 'c1v_grad_finalize')
-            return fin
+            a = L.GradFinalizeArgs(descs.data_ptr(), n, blocks, self.grads.data_ptr(),
+                                   self.sq_partial.data_ptr() if with_sq else None,
+                                   C.cast(C.pointer(loss_args), C.c_void_p) if with_loss else None)
+            return op('c1v_grad_finalize_step', a)
 
         finalize = make_finalize((self.seg_descs, self.n_seg, self.fin_blocks), True, True)
         # data-parallel buckets (reverse layer order): the decoder-side gradients are complete after the
@@ -992,6 +991,43 @@ class VAEEngine:
         for o in ops:
             o()
 
+    def _flat(self, ops):
+        """`ops` with the Python-level stage runner replaced by the launches it issues, or None if an op of the list cannot
+        be recorded (the side-stream backward, ops that are not `f(args*, stream)` entry points)."""
+        out = []
+        for o in ops:
+            if getattr(o, '__func__', None) is VAEEngine._run_backward:
+                if not (os.environ.get('C1V_BWD_PAIR', '1') == '1' or self.g.use_batch_norm):
+                    return None
+                for _, _, fused_ops in self.bwd_stages:
+                    out.extend(fused_ops)
+            elif getattr(o, '__name__', '') == 'mark_stale':
+                continue                                   # (the caller sets the flag, as for graph replays)
+            else:
+                out.append(o)
+        self._list_blockers = [getattr(o, '__name__', repr(o)) for o in out if not hasattr(o, 'c_fn')]    # (diagnostic)
+        return out if not self._list_blockers else None
+
+    def _list(self, key: str, ops) -> bool:
+        """Issue `ops` back to back from native code (c1v_run_list): one ctypes call for the whole step.  False if the list
+        cannot be recorded."""
+        rec = self._lists.get(key)
+        if rec is None:
+            flat = self._flat(ops)
+            if flat is None:
+                self._lists[key] = rec = False
+            else:
+                n = len(flat)
+                fns = (C.c_void_p * n)(*[C.cast(o.c_fn, C.c_void_p) for o in flat])
+                args = (C.c_void_p * n)(*[C.cast(C.pointer(o.c_args), C.c_void_p) for o in flat])
+                self._lists[key] = rec = (n, fns, args, flat)
+        if rec is False:
+            return False
+        rc = self.lib.c1v_run_list(rec[0], rec[1], rec[2], self._stream())
+        if rc != 0:
+            L.check(rc, 'c1v_run_list')
+        return True
+
     def _graph(self, key: str, ops):
         """Run `ops` through a HIP graph captured on first use (eager warm-up first so that one-time kernel
         attribute calls happen outside the capture)."""
@@ -1042,6 +1078,7 @@ class VAEEngine:
         self.in_ids = torch.full((self.B, self.g.input_text_size), -1, dtype=torch.int32, device=self.dev)
         self._build_gather()
         self._graphs = {k: v for k, v in self._graphs.items() if not k.endswith('@ids')}
+        self._lists = {k: v for k, v in self._lists.items() if not k.endswith('@ids')}
 
     def _build_gather(self):
         self._gather_args = L.GatherInputArgs(
@@ -1169,9 +1206,17 @@ class VAEEngine:
         self._dp_all_reduce = all_reduce
         sfx = '@ids' if from_ids else ''
 
+        # How a captured step is issued.  `list` (default for one rank): the recorded launches back to back from native code
+        # (c1v_run_list) -- measured at C2 0.196-0.198 ms against 0.204 ms for the replay of the same launches as a HIP
+        # graph, whose replays the runtime keeps ~8 us apart; `graph`: the HIP graph (always for the data-parallel step,
+        # whose collectives are captured with it).
+        as_list = use_graph and os.environ.get('C1V_STEP_LAUNCH', 'list') == 'list'
+
         def go(key, ops):
             if use_graph:
-                self._graph(key + ('_fixed' if fixed_rng else '') + sfx, ops)
+                k_ = key + ('_fixed' if fixed_rng else '') + sfx
+                if not (as_list and self.world == 1 and not self.force_bucketed and self._list(k_, ops)):
+                    self._graph(k_, ops)
             else:
                 self._run(ops)
 

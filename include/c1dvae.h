@@ -363,6 +363,12 @@ typedef struct c1v_loss_reduce_args {
 } c1v_loss_reduce_args;
 int c1v_grad_finalize_loss(const c1v_seg_desc* segs /*device*/, int32_t n_seg, int32_t total_blocks, float* grad, float* sq_partial,
                            const c1v_loss_reduce_args* loss, void* stream);
+/* both of the above behind ONE argument struct (loss == NULL: no loss scalars), so that the launch can be an entry of
+ * c1v_run_list */
+typedef struct c1v_grad_finalize_args {
+    const c1v_seg_desc* segs; int32_t n_seg, total_blocks; float* grad; float* sq_partial; const c1v_loss_reduce_args* loss;
+} c1v_grad_finalize_args;
+int c1v_grad_finalize_step(const c1v_grad_finalize_args*, void* stream);
 int c1v_sqnorm_partial(const float* x, int64_t n, float* sq_partial, int32_t n_partial, void* stream);
 typedef struct c1v_nadam_args {
     float* p; const float* g; float* m; float* v; int64_t n;
@@ -434,6 +440,14 @@ typedef struct c1v_vocab_argmax_noalloc_args {
     float* score; int32_t* idx;             /* [M] */
 } c1v_vocab_argmax_noalloc_args;
 int c1v_vocab_argmax_noalloc(const c1v_vocab_argmax_noalloc_args*, void* stream);
+
+/* A recorded step: calls fns[i](args[i], stream) for i = 0 .. n-1 and stops at the first non-zero return code (which it
+ * returns).  Every entry point above of the form `int f(const X_args*, void* stream)` can be listed.  Why: a training step at
+ * C2 is 16 launches of 5-50 us; issued one by one from Python the host is the bottleneck, replayed as a HIP graph the runtime
+ * leaves ~8 us between two replays (4 % of the step, profiles/r03a_c2_trace_step.txt), issued back to back from native code
+ * there is no gap.  No counterpart in the reference (Keras' session.run plays this role there). */
+typedef int (*c1v_op_fn)(const void* args, void* stream);
+int c1v_run_list(int32_t n, const c1v_op_fn* fns, const void* const* args, void* stream);
 /* merge per-shard results gathered from R ranks: ties -> lowest global index */
 int c1v_argmax_merge(const float* scores /*[R][M]*/, const int32_t* idxs, int32_t R, int32_t M, float* score, int32_t* idx, void* stream);
 

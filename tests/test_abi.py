@@ -42,7 +42,8 @@ def test_ctypes_struct_sizes_match_the_header(tmp_path):
                'c1v_xent_finish_args': _lib.XentFinishArgs, 'c1v_seg_desc': _lib.SegDesc,
                'c1v_nadam_args': _lib.NadamArgs, 'c1v_vocab_argmax_args': _lib.VocabArgmaxArgs,
                'c1v_rng_desc': _lib.RngDesc, 'c1v_bn_args': _lib.BnArgs,
-               'c1v_vocab_argmax_noalloc_args': _lib.VocabArgmaxNoallocArgs}
+               'c1v_vocab_argmax_noalloc_args': _lib.VocabArgmaxNoallocArgs,
+               'c1v_grad_finalize_args': _lib.GradFinalizeArgs}
     prog = '#include <stdio.h>\n#include "c1dvae.h"\nint main(void){\n'
     for name in structs:
         prog += '  printf("%s %%zu\\n", sizeof(%s));\n' % (name, name)

@@ -354,7 +354,11 @@ def test_nadam_trajectory_parity(dtype):
     np.testing.assert_allclose(got_losses, ref_losses, rtol=1e-3 if dtype == 'f32' else 1e-2)
 
 
-def test_graph_replay_matches_eager_and_is_deterministic():
+@pytest.mark.parametrize('launch', ['list', 'graph'])
+def test_graph_replay_matches_eager_and_is_deterministic(launch, monkeypatch):
+    """The captured step -- issued from native code by c1v_run_list (the default) or replayed as a HIP graph
+    (C1V_STEP_LAUNCH=graph) -- against the same launches issued one by one from Python: same bits, run after run."""
+    monkeypatch.setenv('C1V_STEP_LAUNCH', launch)
     c = CASES['mid']
     og, params, Wv, x, ids, eps, mask_e, mask_d = make_case(c, seed=2)
     res = []
@@ -364,6 +368,8 @@ def test_graph_replay_matches_eager_and_is_deterministic():
         for _ in range(3):
             eng.train_step(use_graph=use_graph, fixed_rng=True)
         torch.cuda.synchronize()
+        assert not use_graph or (len(eng._lists) > 0 and all(eng._lists.values())) == (launch == 'list'), getattr(eng, '_list_blockers', None)
+        assert not use_graph or (len(eng._graphs) > 0) == (launch == 'graph')
         res.append((eng.params.cpu().numpy().copy(), eng.loss()))
     assert np.array_equal(res[0][0], res[1][0]) and res[0][1] == res[1][1]
     assert np.array_equal(res[1][0], res[2][0])
