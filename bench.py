@@ -237,7 +237,7 @@ def hbm_table(eng, g, B, ids, reps=20):
         rows.append({'kernel': name, 'bytes': float(nbytes), 'us': ms * 1e3, 'tb_per_s': nbytes / ms / 1e9,
                      'frac': nbytes / ms / 1e9 / HBM_PEAK_TBS, 'traffic': note})
     slab_bytes = sum(int(t.numel()) * 4 for t in eng.slabs.values())
-    add('grad_finalize_kernel', eng.ops_finalize[0], slab_bytes + eng.P * 4, 'wgrad slabs in, flat fp32 gradient out')
+    add('grad_finalize_kernel', eng.ops_finalize[-1], slab_bytes + eng.P * 4, 'wgrad slabs in, flat fp32 gradient out')
     add('nadam_kernel', [o for o in eng.update_ops() if getattr(o, '__name__', '') != 'mark_stale'][-1], eng.P * 28,
         'p, g, m, v in; p, m, v out (28 B / parameter)')
     core = eng.ops_loss_train_core

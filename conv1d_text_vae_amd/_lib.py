@@ -132,7 +132,7 @@ class SegDesc(C.Structure):
 
 class LossReduceArgs(C.Structure):
     _fields_ = [('xent_rows', C.c_void_p), ('ids', C.c_void_p), ('kl_b', C.c_void_p), ('B', C.c_int32), ('T', C.c_int32),
-                ('B_global', C.c_int32), ('out3', C.c_void_p), ('xent_b', C.c_void_p)]
+                ('B_global', C.c_int32), ('out3', C.c_void_p), ('xent_b', C.c_void_p), ('pre_summed', C.c_int32)]
 
 
 class GradFinalizeArgs(C.Structure):
@@ -223,6 +223,7 @@ SYMBOLS = {
     'c1v_loss_reduce': ([C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
                          C.c_void_p, C.c_void_p], C.c_int),
     'c1v_grad_finalize': ([C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p], C.c_int),
+    'c1v_loss_sample_means': ([_P(LossReduceArgs), C.c_void_p], C.c_int),
     'c1v_grad_finalize_step': ([_P(GradFinalizeArgs), C.c_void_p], C.c_int),
     'c1v_grad_finalize_loss': ([C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, _P(LossReduceArgs), C.c_void_p],
                                C.c_int),

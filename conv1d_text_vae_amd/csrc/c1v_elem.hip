@@ -339,7 +339,7 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
     return r;
 }
 
-struct LossRedDev { const float* xent_rows; const int* ids; const float* kl_b; int B, T, B_global; float* out3; float* xent_b; };
+struct LossRedDev { const float* xent_rows; const int* ids; const float* kl_b; int B, T, B_global; float* out3; float* xent_b; int pre; };
 
 __global__ __launch_bounds__(256) void grad_finalize_kernel(const c1v_seg_desc* __restrict__ segs, int n_seg, float* __restrict__ grad,
                                                             float* __restrict__ sq_partial, int seg_blocks, LossRedDev lr) {
@@ -347,7 +347,7 @@ __global__ __launch_bounds__(256) void grad_finalize_kernel(const c1v_seg_desc* 
     // behind the segment blocks -- and the segment blocks are numbered from 1
     const int first = (int)gridDim.x - seg_blocks;
     if ((int)blockIdx.x < first) {
-        loss_reduce_body(lr.xent_rows, lr.ids, lr.kl_b, lr.B, lr.T, lr.B_global, lr.out3, lr.xent_b);
+        loss_reduce_body(lr.xent_rows, lr.ids, lr.kl_b, lr.B, lr.T, lr.B_global, lr.out3, lr.xent_b, lr.pre != 0);
         return;
     }
     const int blk = (int)blockIdx.x - first;
@@ -447,7 +447,8 @@ extern "C" int c1v_grad_finalize_loss(const c1v_seg_desc* segs, int32_t n_seg, i
                                       const c1v_loss_reduce_args* l, void* stream) {
     C1V_REQUIRE(segs && grad && n_seg > 0 && total_blocks > 0, "grad_finalize_loss: bad argument");
     C1V_REQUIRE(l && l->xent_rows && l->ids && l->out3 && l->B > 0 && l->T > 0 && l->B_global > 0, "grad_finalize_loss: bad loss argument");
-    const LossRedDev lr{l->xent_rows, l->ids, l->kl_b, l->B, l->T, l->B_global, l->out3, l->xent_b};
+    C1V_REQUIRE(!l->pre_summed || l->xent_b, "grad_finalize_loss: pre_summed needs xent_b");
+    const LossRedDev lr{l->xent_rows, l->ids, l->kl_b, l->B, l->T, l->B_global, l->out3, l->xent_b, l->pre_summed};
     hipLaunchKernelGGL(grad_finalize_kernel, dim3((unsigned)total_blocks + 1), dim3(256), 0, (hipStream_t)stream, segs, n_seg, grad, sq_partial,
                        total_blocks, lr);
     C1V_LAUNCH_CHECK();
@@ -835,6 +836,17 @@ __global__ void counter_add_kernel(uint64_t* ctr, uint64_t inc) { if (threadIdx.
 extern "C" int c1v_counter_add(uint64_t* ctr, uint64_t inc, void* stream) {
     C1V_REQUIRE(ctr, "counter_add: null argument");
     hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, ctr, inc);
+    C1V_LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ __launch_bounds__(256) void loss_sample_means_kernel(const float* __restrict__ xent_rows, const int* __restrict__ ids, int B, int T_len,
+                                                                float* __restrict__ xent_b) {
+    loss_sample_means_body(xent_rows, ids, B, T_len, xent_b, (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6));
+}
+extern "C" int c1v_loss_sample_means(const c1v_loss_reduce_args* l, void* stream) {
+    C1V_REQUIRE(l && l->xent_rows && l->ids && l->xent_b && l->B > 0 && l->T > 0, "loss_sample_means: bad argument");
+    hipLaunchKernelGGL(loss_sample_means_kernel, dim3((unsigned)c1v_cdiv(l->B, 4)), dim3(256), 0, (hipStream_t)stream, l->xent_rows, l->ids, l->B, l->T, l->xent_b);
     C1V_LAUNCH_CHECK();
     return 0;
 }

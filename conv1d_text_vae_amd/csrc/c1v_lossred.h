@@ -6,7 +6,9 @@
 // (one workgroup of any whole number of waves <= 16; also run as an extra block of grad_finalize)
 __device__ __forceinline__ void loss_reduce_body(const float* __restrict__ xent_rows, const int* __restrict__ ids,
                                                  const float* __restrict__ kl_b, int B, int T_len, int B_global,
-                                                 float* __restrict__ out3, float* __restrict__ xent_b) {
+                                                 float* __restrict__ out3, float* __restrict__ xent_b, const bool pre = false) {
+    // pre: xent_b already holds the per-sample means (c1v_loss_sample_means: large batches -- 270 k rows at C4 kept this
+    // single block busy for 70 us, twice as long as the rest of grad_finalize); only the sums over the samples are left.
     // Thread i owns sample i: it reads the T per-step values and ids of its row with independent 16-byte loads (all in
     // flight together: one memory round trip per sample, no LDS staging, no barrier) and sums them in step order.  Every
     // sum has a fixed order.
@@ -14,7 +16,10 @@ __device__ __forceinline__ void loss_reduce_body(const float* __restrict__ xent_
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x, nwave = nthr >> 6;
     float ax = 0.f, ak = 0.f;
     constexpr int LR_TMAX = 128;                   // longest row a single thread sums
-    if (T_len <= LR_TMAX) {
+    if (pre) {
+        for (int b = tid; b < B && tid < 256; b += 256) { ax += xent_b[b]; ak += kl_b ? kl_b[b] : 0.f; }
+        ax = wave_sum(ax); ak = wave_sum(ak);
+    } else if (T_len <= LR_TMAX) {
         const bool vec = (T_len & 3) == 0 && (((((uintptr_t)xent_rows) | ((uintptr_t)ids)) & 15) == 0);
         // samples go to the first 256 threads whatever the block size, so the order of every sum (and the result, bit for
         // bit) is the same in the stand-alone kernel and as a block of grad_finalize
@@ -63,6 +68,16 @@ __device__ __forceinline__ void loss_reduce_body(const float* __restrict__ xent_
     }
 }
 
+// per-sample means for loss_reduce_body(pre = true): one wave per sample, lanes over the steps, fixed order
+__device__ __forceinline__ void loss_sample_means_body(const float* __restrict__ xent_rows, const int* __restrict__ ids, int B, int T_len,
+                                                       float* __restrict__ xent_b, int b) {
+    if (b >= B) return;
+    const int lane = threadIdx.x & 63;
+    float s = 0.f, c = 0.f;
+    for (int t = lane; t < T_len; t += 64) { s += xent_rows[(int64_t)b * T_len + t]; c += ids[(int64_t)b * T_len + t] >= 0 ? 1.f : 0.f; }
+    s = wave_sum_dpp(s); c = wave_sum_dpp(c);
+    if (lane == 0) xent_b[b] = s / c;
+}
 
 constexpr int VS_BM_ROWS = 128;   // sample rows per workgroup of the vocabulary stream kernel
 constexpr int VS_CUS = 256;       // compute units of an MI355X: workgroups of the stream kernel that run at the same time

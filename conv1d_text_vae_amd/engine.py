@@ -896,9 +896,13 @@ class VAEEngine:
         n_partial = 256 if bucketed else self.fin_blocks
 
         f_fin_loss = self.lib.c1v_grad_finalize_loss
+        # large batches: the per-sample means in a launch of their own (one wave per sample) instead of inside the single
+        # loss workgroup of grad_finalize (C4: that block took 70 us, the rest of the launch 31)
+        pre = 1 if B * g.output_text_size >= int(os.environ.get('C1V_LOSS_PRESUM_MIN_ROWS', '65536')) else 0
         loss_args = L.LossReduceArgs(self.xent_rows.data_ptr(), self.ids_in.data_ptr(), self.kl_b.data_ptr(), B,
-                                     g.output_text_size, self.Bg, self.loss_out.data_ptr(), self.xent_b.data_ptr())
+                                     g.output_text_size, self.Bg, self.loss_out.data_ptr(), self.xent_b.data_ptr(), pre)
         self._keep.append(loss_args)
+        presum = [op('c1v_loss_sample_means', loss_args)] if pre else []
 
         def make_finalize(table, with_sq, with_loss):
             """Sum the wgrad slabs of the table's segments into the flat gradient; with_loss: the step's loss scalars
@@ -925,7 +929,14 @@ class VAEEngine:
         assert 0 < off_h < off_d < self.P and all((self.seg_off[n] < off_h) == is_conv(n) and
                                                   (self.seg_off[n] >= off_d) == (not is_enc(n)) for n in self.seg_names)
         # (bucket = backward stages [previous hi, hi), finalize launch over its segments, contiguous slice of `grads`)
-        self.dp_buckets = [(nd + 2, make_finalize(seg_table(lambda n: not is_enc(n)), False, True), (off_d, self.P))]
+        fin_dec = make_finalize(seg_table(lambda n: not is_enc(n)), False, True)
+        if presum:
+            fin_dec_only = fin_dec
+
+            def fin_dec():
+                presum[0]()
+                fin_dec_only()
+        self.dp_buckets = [(nd + 2, fin_dec, (off_d, self.P))]
         if os.environ.get('C1V_DP_BUCKETS', '3') == '3':
             self.dp_buckets += [(nd + 3, make_finalize(seg_table(is_heads), False, False), (off_h, off_d)),
                                 (None, make_finalize(seg_table(is_conv), False, False), (0, off_h))]
@@ -939,7 +950,7 @@ class VAEEngine:
             L.check(f_adv(self.nadam_state.data_ptr(), self.sched.data_ptr(), self.sq_partial.data_ptr(), n_partial,
                           self.step_ctr.data_ptr(), self._stream()), 'c1v_nadam_advance')
 
-        self.ops_finalize = [finalize]
+        self.ops_finalize = presum + [finalize]
         nad = L.NadamArgs(self.params.data_ptr(), self.grads.data_ptr(), self.nadam_m.data_ptr(), self.nadam_v.data_ptr(),
                           self.P, 1.0, CLIPNORM, self.sched.data_ptr(), 0.9, 0.999, 1e-7, self.norm_out.data_ptr())
         self.ops_update = ([sqnorm] if bucketed else []) + [advance, op('c1v_nadam_step', nad), self._pack_all]

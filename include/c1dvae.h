@@ -360,7 +360,12 @@ int c1v_grad_finalize(const c1v_seg_desc* segs /*device*/, int32_t n_seg, int32_
  * the same launch: both close the backward pass and the scalars are off the critical path. */
 typedef struct c1v_loss_reduce_args {
     const float* xent_rows; const int32_t* ids; const float* kl_b; int32_t B, T, B_global; float* out3; float* xent_b;
+    int32_t pre_summed;   /* 1: xent_b already holds the per-sample means (c1v_loss_sample_means); only the sums over b are left */
 } c1v_loss_reduce_args;
+/* the per-sample part of c1v_loss_reduce as a launch of its own, one wave per sample: xent_b[b] = sum_t xent_rows[b,t] / #targets.
+ * For large batches (C4: 270 k rows), where the single workgroup of c1v_grad_finalize_loss was twice as long as the rest of
+ * that launch. */
+int c1v_loss_sample_means(const c1v_loss_reduce_args*, void* stream);
 int c1v_grad_finalize_loss(const c1v_seg_desc* segs /*device*/, int32_t n_seg, int32_t total_blocks, float* grad, float* sq_partial,
                            const c1v_loss_reduce_args* loss, void* stream);
 /* both of the above behind ONE argument struct (loss == NULL: no loss scalars), so that the launch can be an entry of

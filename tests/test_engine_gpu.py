@@ -354,6 +354,29 @@ def test_nadam_trajectory_parity(dtype):
     np.testing.assert_allclose(got_losses, ref_losses, rtol=1e-3 if dtype == 'f32' else 1e-2)
 
 
+@pytest.mark.parametrize('name', ['mid', 'deep3'])
+def test_loss_scalars_with_the_per_sample_means_in_their_own_launch(name, monkeypatch):
+    """Large batches (>= 65 536 target rows) sum the per-step losses of a sample in c1v_loss_sample_means (one wave per
+    sample) instead of inside the single loss workgroup of c1v_grad_finalize_loss; forced here on small cases: the
+    gradients are the same bits, the loss scalars agree to rounding (another order of the T additions per sample)."""
+    c = CASES[name]
+    og, params, Wv, x, ids, eps, mask_e, mask_d = make_case(c)
+    got = {}
+    for rows in ('1', '1000000000'):
+        monkeypatch.setenv('C1V_LOSS_PRESUM_MIN_ROWS', rows)
+        eng = build_engine(c, og, params, Wv, 'bf16')
+        assert len(eng.ops_finalize) == (2 if rows == '1' else 1)
+        load_fixed(eng, x, ids, eps, mask_e, mask_d)
+        eng._run(eng.train_ops(False))
+        torch.cuda.synchronize()
+        got[rows] = (eng.get_grads(), eng.loss_out.cpu().numpy().copy(), eng.xent_b.cpu().numpy().copy())
+    a, b = got['1'], got['1000000000']
+    np.testing.assert_allclose(a[1], b[1], rtol=1e-6)
+    np.testing.assert_allclose(a[2], b[2], rtol=1e-6)
+    for k_, v in b[0].items():
+        np.testing.assert_array_equal(a[0][k_], v, err_msg=k_)
+
+
 @pytest.mark.parametrize('launch', ['list', 'graph'])
 def test_graph_replay_matches_eager_and_is_deterministic(launch, monkeypatch):
     """The captured step -- issued from native code by c1v_run_list (the default) or replayed as a HIP graph

@@ -42,7 +42,7 @@ def op_list(eng, g):
                 ops.append((n + ' wgrad', o))
             for o in main:
                 ops.append((n + ' dgrad', o))
-    ops.append(('grad_finalize', eng.ops_finalize[0]))
+    ops.append(('grad_finalize', eng.ops_finalize[-1]))
     upd = [o for o in eng.update_ops() if getattr(o, '__name__', '') != 'mark_stale']
     ops += [('nadam' if i == len(upd) - 1 else 'update%d' % i, o) for i, o in enumerate(upd)]
     return ops
