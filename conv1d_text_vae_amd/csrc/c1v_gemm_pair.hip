@@ -4,12 +4,37 @@
 // dgrad tiles.  Measured before this (rocprofv3 kernel trace of the captured step): the two chains on two streams
 // overlapped little -- every cross-queue dependency of the graph cost 5-10 us.
 #include "c1v_gemm_dev.h"
+#include <stdlib.h>
 
 struct PairParams {
     NtParams nt;
     TnParams tn;
     int tn_gi, tn_gij, tn_blocks, nt_gm;
+    int tn_xcd, tn_gj, tn_groups;      // XCD-aware deal of the wgrad workgroups (pair_tn_tile)
 };
+
+// Which wgrad tile workgroup `id` of the grid runs.  Plain deal: id -> (tap * splits + split, by, bx), tile index fastest.
+// XCD-aware deal (tn_xcd): workgroups go to the XCDs round-robin (XCD = id % 8), and the workgroups that read the same rows
+// of the same operand columns -- the gj column tiles x taps of one (row split, bx) -- are all given to ONE XCD, so that
+// its L2 fetches those rows once instead of every XCD fetching them (per-launch FETCH_SIZE of the paired launches at C4
+// showed 1.5-2.3 x the operand bytes).  Groups are dealt to the XCDs round-robin; the grid is padded to whole rounds of
+// eight groups, the padding workgroups return false.
+__device__ __forceinline__ bool pair_tn_tile(const PairParams& pp, int id, int& bx, int& by, int& bz) {
+    if (!pp.tn_xcd) {
+        bz = id / pp.tn_gij;
+        const int r = id - bz * pp.tn_gij;
+        by = r / pp.tn_gi; bx = r - by * pp.tn_gi;
+        return true;
+    }
+    const int grp = pp.tn_gj * pp.tn.taps;
+    const int xcd = id & 7, slot = id >> 3;
+    const int g = xcd + 8 * (slot / grp), w = slot % grp;
+    if (g >= pp.tn_groups) return false;
+    const int split = g / pp.tn_gi, tap = w / pp.tn_gj;
+    bx = g - split * pp.tn_gi; by = w - tap * pp.tn_gj;
+    bz = tap * pp.tn.splits + split;
+    return true;
+}
 
 template <typename T, int BM, int BN, int NS>
 __global__ __launch_bounds__(C1V_GEMM_THREADS) void gemm_pair_kernel(const PairParams pp) {
@@ -17,8 +42,8 @@ __global__ __launch_bounds__(C1V_GEMM_THREADS) void gemm_pair_kernel(const PairP
     c1v_touch_kernarg<7>();
     const int id = blockIdx.x;
     if (id < pp.tn_blocks) {
-        const int bz = id / pp.tn_gij, r = id - bz * pp.tn_gij;
-        const int by = r / pp.tn_gi, bx = r - by * pp.tn_gi;
+        int bx, by, bz;
+        if (!pair_tn_tile(pp, id, bx, by, bz)) return;
         tn_body<T>(pp.tn, bx, by, bz);
     } else {
         const int r = id - pp.tn_blocks;
@@ -33,8 +58,8 @@ __global__ __launch_bounds__(C1V_GEMM_THREADS, 3) void gemm_pair_large_kernel(co
     c1v_touch_kernarg<7>();
     const int id = blockIdx.x;
     if (id < pp.tn_blocks) {
-        const int bz = id / pp.tn_gij, r = id - bz * pp.tn_gij;
-        const int by = r / pp.tn_gi, bx = r - by * pp.tn_gi;
+        int bx, by, bz;
+        if (!pair_tn_tile(pp, id, bx, by, bz)) return;
         tn_body<T>(pp.tn, bx, by, bz);
     } else {
         // (r % 8 names the XCD as well as id % 8 does: the same shift for every workgroup)
@@ -52,8 +77,8 @@ __global__ __launch_bounds__(C1V_GEMM_THREADS, 3) void gemm_pair_ntw_kernel(cons
     c1v_touch_kernarg<7>();
     const int id = blockIdx.x;
     if (id < pp.tn_blocks) {
-        const int bz = id / pp.tn_gij, r = id - bz * pp.tn_gij;
-        const int by = r / pp.tn_gi, bx = r - by * pp.tn_gi;
+        int bx, by, bz;
+        if (!pair_tn_tile(pp, id, bx, by, bz)) return;
         tn_body<T>(pp.tn, bx, by, bz);
     } else {
         const int r = id - pp.tn_blocks;
@@ -132,7 +157,14 @@ int c1v_launch_pair(int dtype, const NtParams& nt, const TnParams& tn, hipStream
     pp.nt = nt; pp.tn = tn;
     pp.tn_gi = (int)c1v_cdiv(tn.I, 128);
     pp.tn_gij = pp.tn_gi * (int)c1v_cdiv(tn.J, 128);
-    const int64_t tn_blocks = (int64_t)pp.tn_gij * tn.taps * tn.splits;
+    int64_t tn_blocks = (int64_t)pp.tn_gij * tn.taps * tn.splits;
+    pp.tn_gj = pp.tn_gij / pp.tn_gi;
+    pp.tn_groups = tn.splits * pp.tn_gi;
+    // the XCD-aware deal pays when there is something to share (several workgroups per group) and enough groups to keep the
+    // eight XCDs evenly loaded (C1V_TN_XCD=0 / 1: never / always)
+    const char* env = getenv("C1V_TN_XCD");
+    pp.tn_xcd = env ? (env[0] == '1') : (pp.tn_gj * tn.taps >= 2 && pp.tn_groups >= 16);
+    if (pp.tn_xcd) tn_blocks = 8 * c1v_cdiv(pp.tn_groups, 8) * pp.tn_gj * tn.taps;
     C1V_REQUIRE(tn_blocks < (1ll << 30), "pair launch: too many wgrad tiles");
     pp.tn_blocks = (int)tn_blocks;
     return dtype == C1V_F32 ? launch_pair_t<float>(pp, st) : launch_pair_t<bf16_raw>(pp, st);

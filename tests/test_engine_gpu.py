@@ -354,6 +354,27 @@ def test_nadam_trajectory_parity(dtype):
     np.testing.assert_allclose(got_losses, ref_losses, rtol=1e-3 if dtype == 'f32' else 1e-2)
 
 
+@pytest.mark.parametrize('name', ['deep3', 'k4', 'mid', 'wide', 'big128'])
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_xcd_aware_deal_of_the_paired_wgrad_workgroups_is_bit_identical(name, dtype, monkeypatch):
+    """C1V_TN_XCD: the wgrad workgroups of a paired backward launch dealt so that the tiles and taps of one (row split, bx)
+    run on one XCD (padding workgroups return at once) against the plain deal: the same tiles, the same sums."""
+    c = CASES[name]
+    og, params, Wv, x, ids, eps, mask_e, mask_d = make_case(c)
+    got = {}
+    for mode in ('1', '0'):
+        monkeypatch.setenv('C1V_TN_XCD', mode)
+        eng = build_engine(c, og, params, Wv, dtype)
+        load_fixed(eng, x, ids, eps, mask_e, mask_d)
+        eng._run(eng.train_ops(False))
+        torch.cuda.synchronize()
+        got[mode] = (eng.get_grads(), eng.loss(), eng.mlv.cpu().numpy())
+    assert got['1'][1] == got['0'][1]
+    np.testing.assert_array_equal(got['1'][2], got['0'][2])
+    for k_, v in got['0'][0].items():
+        np.testing.assert_array_equal(got['1'][0][k_], v, err_msg=k_)
+
+
 @pytest.mark.parametrize('name', ['mid', 'deep3'])
 def test_loss_scalars_with_the_per_sample_means_in_their_own_launch(name, monkeypatch):
     """Large batches (>= 65 536 target rows) sum the per-step losses of a sample in c1v_loss_sample_means (one wave per
