@@ -94,6 +94,12 @@ extern "C" int c1v_debug_read(unsigned long long* dst, int n) {
 #else
 #define VS_T(i) do {} while (0)
 #endif
+//   -DVS_PROLOGUE_OVERLAP=1  (round 3) the prologue's requests ordered tile 0 | Yhat | tile 1, a counted wait for tile 0 only and
+//                      the first tile peeled so that its MFMAs wait for Yhat k-step by k-step: parity-green, measured at C2
+//                      49.8 us against 48.8 (the first tile's barrier waits for everything half a tile later anyway)
+#ifndef VS_PROLOGUE_OVERLAP
+#define VS_PROLOGUE_OVERLAP 0
+#endif
 constexpr int VS_BN = 64;     // vocabulary rows per LDS tile
 constexpr int VS_BM = VS_BM_ROWS;    // sample rows per workgroup (4 waves x 32)
 constexpr int VS_STAGES = 3;  // LDS ring of vocabulary tiles
@@ -194,11 +200,14 @@ void vocab_stream_kernel(const bf16_raw* __restrict__ yhat, int M, const bf16_ra
 #define VS_LOAD_PIECE(tb_, i_) R[i_] = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, src_off[i_], (tb_), 0)
     auto tile_base = [&](int t) -> int { return __builtin_amdgcn_readfirstlane(t * (VS_BN * Cfg::ROWB)); };   // bytes, < 2^31 (host check)
 #define VS_WRITE_PIECE(stage_, i_) *(u32x4_t*)(smem + (stage_) * Cfg::STAGE + (wave + 4 * (i_)) * 1024 + lane * 16) = R[i_]
+    // Order of the prologue's requests (they complete in order): tile 0, the Yhat fragments, tile 1.  The wait in front of
+    // the first barrier covers tile 0 only (this wave's pieces); the first tile -- a copy of the loop body of its own, below,
+    // so that the compiler counts its waits per k-step -- starts when its first k-steps of Yhat are there, and the rest of
+    // Yhat and tile 1 (most of the 42 KiB a wave asks for, fetched at the ~11 B/clk a CU gets while every workgroup of the
+    // launch does the same) arrive under its MFMAs.  ACCUM only: the other modes' first barrier sits inside the tile.
+    constexpr bool OVERLAP = MODE == VS_ACCUM && VS_PROLOGUE_OVERLAP != 0;
     if (t_begin < t_end) stage_tile(t_begin, 0);
-    if constexpr (REGFEED) {
-#pragma unroll
-        for (int i = 0; i < Cfg::PPW; ++i) VS_LOAD_PIECE(tile_base(t_begin + 1 < t_end ? t_begin + 1 : t_end - 1), i);
-    } else {
+    if constexpr (!REGFEED && !OVERLAP) {
         if (t_begin + 1 < t_end) stage_tile(t_begin + 1, 1);
     }
 
@@ -210,9 +219,22 @@ void vocab_stream_kernel(const bf16_raw* __restrict__ yhat, int M, const bf16_ra
         const uint4* yp = (const uint4*)(yhat + (int64_t)(m_row < M ? m_row : 0) * Cfg::KP) + h;
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-            uint4 v = (m_row < M) ? yp[2 * s] : make_uint4(0, 0, 0, 0);
+            // (OVERLAP: unconditional -- a lane behind the last row reads row 0 again and computes a copy of its results, which
+            // nothing consumes: every sample row is a column of its own in S, E and U.  A load under `if` is a basic block of its
+            // own, and the compiler then waits for ALL of them in front of the first MFMA instead of k-step by k-step)
+            uint4 v;
+            if constexpr (OVERLAP) v = yp[2 * s];
+            else v = (m_row < M) ? yp[2 * s] : make_uint4(0, 0, 0, 0);
             yf[mb][s] = __builtin_bit_cast(bf16x8_t, v);
         }
+    }
+
+    if constexpr (REGFEED) {
+#pragma unroll
+        for (int i = 0; i < Cfg::PPW; ++i) VS_LOAD_PIECE(tile_base(t_begin + 1 < t_end ? t_begin + 1 : t_end - 1), i);
+    } else if constexpr (OVERLAP) {
+        // (a last tile is requested twice rather than under a branch: the counted wait below assumes PPW requests)
+        if (t_begin < t_end) stage_tile(t_begin + 1 < t_end ? t_begin + 1 : t_begin, 1);
     }
 
     f32x16_t U[MODE == VS_ACCUM ? CB : 1];
@@ -231,7 +253,13 @@ void vocab_stream_kernel(const bf16_raw* __restrict__ yhat, int M, const bf16_ra
     // Both requests and the yf loads (one-time cost).  The BUILTIN form on purpose: the compiler's own bookkeeping must
     // see that the yf loads are complete, or it keeps a `vmcnt(0)` in front of the first MFMA of EVERY tile (an asm wait
     // is invisible to it), which waits for the LDS-DMA request issued a few instructions earlier.
-    __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0), expcnt / lgkmcnt untouched
+    if constexpr (OVERLAP) {
+        constexpr int VMW = KS * MB + Cfg::PPW;            // requests behind tile 0's: Yhat fragments + tile 1
+        static_assert(VMW < 64, "vmcnt is a 6-bit counter");
+        __builtin_amdgcn_s_waitcnt(((VMW >> 4) << 14) | 0x0F70 | (VMW & 15));
+    } else {
+        __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0), expcnt / lgkmcnt untouched
+    }
     asm volatile("" ::: "memory");
     __syncthreads();
 
@@ -532,9 +560,21 @@ void vocab_stream_kernel(const bf16_raw* __restrict__ yhat, int M, const bf16_ra
             }
         }
     };
-    for (int t = t_begin; t < t_end; ++t) {
-        if (MODE != VS_ACCUM && t * VS_BN + VS_BN > N) tile_body(t, std::true_type{});
-        else tile_body(t, std::false_type{});
+    if constexpr (OVERLAP) {
+        // the first tile (see the prologue), then the loop -- entered from that tile only, so that the compiler knows every
+        // Yhat fragment to have arrived and puts no vmcnt wait into the loop (one there would also wait for the LDS-DMA
+        // requests, which it cannot see)
+        if (t_begin < t_end) {
+            tile_body(t_begin, std::false_type{});
+            for (int t = t_begin + 1; t < t_end; ++t) tile_body(t, std::false_type{});
+        } else {
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+        }
+    } else {
+        for (int t = t_begin; t < t_end; ++t) {
+            if (MODE != VS_ACCUM && t * VS_BN + VS_BN > N) tile_body(t, std::true_type{});
+            else tile_body(t, std::false_type{});
+        }
     }
 #ifdef VS_STAMP
     unsigned long long tloop;
