@@ -1039,6 +1039,13 @@ class VAEEngine:
             L.check(rc, 'c1v_run_list')
         return True
 
+    def _launch(self, key: str, ops):
+        """A recorded op list of the inference / validation entry points: from native code if every op can be listed
+        (c1v_run_list), else as a HIP graph."""
+        if os.environ.get('C1V_STEP_LAUNCH', 'list') == 'list' and self._list(key, ops):
+            return
+        self._graph(key, ops)
+
     def _graph(self, key: str, ops):
         """Run `ops` through a HIP graph captured on first use (eager warm-up first so that one-time kernel
         attribute calls happen outside the capture)."""
@@ -1292,7 +1299,7 @@ class VAEEngine:
         ops = ([] if fixed_rng else self.ops_rng_eval) + self.ops_live_first + self._in_ops(from_ids) + self.ops_enc_infer + \
             self.ops_lat_eval + self.ops_dec_eval + self.ops_loss_eval
         if use_graph:
-            self._graph(('eval_fixed' if fixed_rng else 'eval') + ('@ids' if from_ids else ''), ops)
+            self._launch(('eval_fixed' if fixed_rng else 'eval') + ('@ids' if from_ids else ''), ops)
         else:
             self._run(ops)
 
@@ -1303,7 +1310,7 @@ class VAEEngine:
         ops = self.ops_rng_eval + self._in_ops(from_ids) + self.ops_enc_infer + self.ops_lat_eval + self.ops_dec_infer + \
             (self.ops_post if postprocess else [])
         if use_graph:
-            self._graph('sample_recon' + ('_post' if postprocess else '') + ('@ids' if from_ids else ''), ops)
+            self._launch('sample_recon' + ('_post' if postprocess else '') + ('@ids' if from_ids else ''), ops)
         else:
             self._run(ops)
         return self.post if postprocess else self.y_pred()
@@ -1316,7 +1323,7 @@ class VAEEngine:
         self._ensure_packed()
         ops = self.ops_pack_in + self.ops_enc_infer + (self.ops_lat_infer if self.heads_splits > 1 else [])   # sums the slabs
         if use_graph:
-            self._graph('encode', ops)
+            self._launch('encode', ops)
         else:
             self._run(ops)
         return self.mlv[:, :self.D]
@@ -1326,7 +1333,7 @@ class VAEEngine:
         self._ensure_packed()
         ops = self.ops_pack_in + self.ops_enc_infer + self.ops_lat_infer + self.ops_dec_infer + (self.ops_post if postprocess else [])
         if use_graph:
-            self._graph('recon_post' if postprocess else 'recon', ops)
+            self._launch('recon_post' if postprocess else 'recon', ops)
         else:
             self._run(ops)
         return self.post if postprocess else self._y_view()

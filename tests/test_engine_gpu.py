@@ -32,6 +32,8 @@ CASES = {
     'kp256': dict(B=6, T_in=14, T_out=15, E=200, n_filters=(24,), k=3, D=12, N=700),  # 200-d embeddings
     'kp384': dict(B=4, T_in=12, T_out=12, E=340, n_filters=(16,), k=3, D=8, N=300),   # wider than any fused kernel: unfused path
     'big128': dict(B=2048, T_in=32, T_out=32, E=62, n_filters=(128,), k=3, D=32, N=200),   # 128x128 GEMM tiles (>= 384 of them)
+    'kp320': dict(B=6, T_in=14, T_out=13, E=316, n_filters=(64,), k=3, D=12, N=300),   # V = 318: the widest fused row (kp = 320), whole-row out conv in bf16
+    'ragged': dict(B=37, T_in=11, T_out=9, E=62, n_filters=(64,), k=3, D=8, N=150),    # 37 samples x odd lengths: whole-row tiles straddle samples and end ragged
     'longflat': dict(B=8, T_in=70, T_out=20, E=30, n_filters=(64,), k=3, D=16, N=90),   # flat = 2176: split-K heads GEMM (8 slabs)
 }
 
@@ -245,7 +247,7 @@ def test_wide_window_nt_variant_is_bit_identical(name, dtype, monkeypatch):
             np.testing.assert_array_equal(got[mode][0][k_], v, err_msg=k_)
 
 
-@pytest.mark.parametrize('name', ['deep3', 'k4', 'k2', 'mid', 'wide', 'big128'])
+@pytest.mark.parametrize('name', ['deep3', 'k4', 'k2', 'mid', 'wide', 'big128', 'kp320', 'ragged'])
 @pytest.mark.parametrize('dtype', ['f32', 'bf16'])
 def test_output_convolution_with_fused_l2norm(name, dtype, monkeypatch):
     """C1V_ROW_NORM (the output convolution's workgroup holds whole rows and l2-normalises them in its epilogue: yhat at the
