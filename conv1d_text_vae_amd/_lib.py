@@ -135,6 +135,13 @@ class LossReduceArgs(C.Structure):
                 ('B_global', C.c_int32), ('out3', C.c_void_p), ('xent_b', C.c_void_p), ('pre_summed', C.c_int32)]
 
 
+WGRAD_BATCH_MAX = 12
+
+
+class WgradBatchArgs(C.Structure):
+    _fields_ = [('n', C.c_int32), ('items', C.POINTER(WgradArgs) * WGRAD_BATCH_MAX)]
+
+
 class GradFinalizeArgs(C.Structure):
     _fields_ = [('segs', C.c_void_p), ('n_seg', C.c_int32), ('total_blocks', C.c_int32), ('grad', C.c_void_p),
                 ('sq_partial', C.c_void_p), ('loss', C.c_void_p)]
@@ -223,6 +230,7 @@ SYMBOLS = {
     'c1v_loss_reduce': ([C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
                          C.c_void_p, C.c_void_p], C.c_int),
     'c1v_grad_finalize': ([C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p], C.c_int),
+    'c1v_wgrad_batch': ([_P(WgradBatchArgs), C.c_void_p], C.c_int),
     'c1v_loss_sample_means': ([_P(LossReduceArgs), C.c_void_p], C.c_int),
     'c1v_grad_finalize_step': ([_P(GradFinalizeArgs), C.c_void_p], C.c_int),
     'c1v_grad_finalize_loss': ([C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, _P(LossReduceArgs), C.c_void_p],

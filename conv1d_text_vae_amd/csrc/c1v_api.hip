@@ -187,6 +187,19 @@ extern "C" int c1v_conv1d_wgrad(const c1v_wgrad_args* a, void* s) { return c1v_w
 extern "C" int c1v_deconv1d_wgrad(const c1v_wgrad_args* a, void* s) { return c1v_wgrad(a, s); }
 extern "C" int c1v_dense_wgrad(const c1v_wgrad_args* a, void* s) { return c1v_wgrad(a, s); }
 
+// ---- several weight gradients in one launch ---------------------------------------------------------------
+extern "C" int c1v_wgrad_batch(const c1v_wgrad_batch_args* a, void* stream) {
+    C1V_REQUIRE(a && a->n >= 1 && a->n <= C1V_WGRAD_BATCH_MAX, "wgrad_batch: 1..%d problems", C1V_WGRAD_BATCH_MAX);
+    static_assert(C1V_WGRAD_BATCH_MAX == C1V_TN_MULTI_MAX, "header and kernel agree on the batch size");
+    TnParams ps[C1V_TN_MULTI_MAX];
+    for (int k = 0; k < a->n; ++k) {
+        C1V_REQUIRE(a->items[k], "wgrad_batch: item %d is null", k);
+        if (wgrad_params(a->items[k], ps[k])) return -1;
+        C1V_REQUIRE(a->items[k]->dtype == a->items[0]->dtype, "wgrad_batch: the problems' operand types differ");
+    }
+    return c1v_launch_tn_multi(a->items[0]->dtype, ps, a->n, (hipStream_t)stream);
+}
+
 // ---- recorded step --------------------------------------------------------------------------------------
 extern "C" int c1v_run_list(int32_t n, const c1v_op_fn* fns, const void* const* args, void* stream) {
     C1V_REQUIRE(n >= 0 && (n == 0 || (fns && args)), "run_list: null argument");

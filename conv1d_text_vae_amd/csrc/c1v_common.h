@@ -151,6 +151,8 @@ struct TnParams {
 
 int c1v_launch_nt(int dtype, const NtParams& p, hipStream_t st);
 int c1v_launch_tn(int dtype, const TnParams& p, hipStream_t st);
+constexpr int C1V_TN_MULTI_MAX = 12;
+int c1v_launch_tn_multi(int dtype, const TnParams* ps, int n, hipStream_t st);
 int c1v_launch_pair(int dtype, const NtParams& nt, const TnParams& tn, hipStream_t st);
 int c1v_check_nt(const NtParams& p);
 int c1v_check_tn(const TnParams& p);

@@ -42,6 +42,27 @@ __global__ __launch_bounds__(C1V_GEMM_THREADS) void gemm_tn_kernel(const TnParam
     tn_body<T>(p, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
+// Several weight gradients in ONE launch (c1v_wgrad_batch): small batches, where every wgrad is a few dozen workgroups and
+// its launch is as long as its longest workgroup.  A linear grid; problem k owns workgroups [first[k], first[k+1]).
+struct TnMulti {
+    int n;
+    int first[C1V_TN_MULTI_MAX + 1], gi[C1V_TN_MULTI_MAX], gij[C1V_TN_MULTI_MAX];
+    TnParams p[C1V_TN_MULTI_MAX];
+};
+template <typename T>
+__global__ __launch_bounds__(C1V_GEMM_THREADS) void gemm_tn_multi_kernel(const TnMulti m) {
+    const int id = blockIdx.x;
+    int k = 0;
+#pragma unroll
+    for (int i = 1; i < C1V_TN_MULTI_MAX; ++i)
+        if (i < m.n && id >= m.first[i]) k = i;
+    k = __builtin_amdgcn_readfirstlane(k);
+    const int local = id - m.first[k], gi = m.gi[k], gij = m.gij[k];
+    const int bz = local / gij, r = local - bz * gij;
+    const int by = r / gi, bx = r - by * gi;
+    tn_body<T>(m.p[k], bx, by, bz);
+}
+
 // Fused-tap wgrad: a linear grid, dealt to (tile, tap group, row split) so that the workgroups which read the SAME rows --
 // the 128 x 128 tiles and tap groups of one row split -- are dispatched back to back to ONE XCD (workgroups go to the XCDs
 // round-robin; XCD k = id % 8 owns the row splits k, k + 8, ...) and share its L2 copy of both operands.  With the plain
@@ -190,6 +211,33 @@ template <typename T> static int launch_tn_t(const TnParams& p, hipStream_t st) 
 int c1v_launch_tn(int dtype, const TnParams& p, hipStream_t st) {
     if (c1v_check_tn(p)) return -1;
     return dtype == C1V_F32 ? launch_tn_t<float>(p, st) : launch_tn_t<bf16_raw>(p, st);
+}
+
+int c1v_launch_tn_multi(int dtype, const TnParams* ps, int n, hipStream_t st) {
+    C1V_REQUIRE(ps && n >= 1 && n <= C1V_TN_MULTI_MAX, "wgrad batch: 1..%d problems", C1V_TN_MULTI_MAX);
+    TnMulti m{};
+    m.n = n;
+    int64_t blocks = 0;
+    for (int k = 0; k < n; ++k) {
+        if (c1v_check_tn(ps[k])) return -1;
+        C1V_REQUIRE(ps[k].tg == 0, "wgrad batch: fused-tap problems are launches of their own");
+        m.p[k] = ps[k];
+        m.gi[k] = (int)c1v_cdiv(ps[k].I, 128);
+        m.gij[k] = m.gi[k] * (int)c1v_cdiv(ps[k].J, 128);
+        m.first[k] = (int)blocks;
+        blocks += (int64_t)m.gij[k] * ps[k].taps * ps[k].splits;
+        C1V_REQUIRE(blocks < (1ll << 30), "wgrad batch: too many tiles");
+    }
+    for (int k = n; k <= C1V_TN_MULTI_MAX; ++k) m.first[k] = (int)blocks;
+    if (dtype == C1V_F32) {
+        static bool once = (set_lds(gemm_tn_multi_kernel<float>, TN_LDS), true); (void)once;
+        hipLaunchKernelGGL((gemm_tn_multi_kernel<float>), dim3((unsigned)blocks), dim3(C1V_GEMM_THREADS), TN_LDS, st, m);
+    } else {
+        static bool once = (set_lds(gemm_tn_multi_kernel<bf16_raw>, TN_LDS), true); (void)once;
+        hipLaunchKernelGGL((gemm_tn_multi_kernel<bf16_raw>), dim3((unsigned)blocks), dim3(C1V_GEMM_THREADS), TN_LDS, st, m);
+    }
+    C1V_LAUNCH_CHECK();
+    return 0;
 }
 
 int c1v_fill_epi(const c1v_epilogue& e, EpiDev& d, int M, int Le, int nrows, int N) {

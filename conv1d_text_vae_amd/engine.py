@@ -757,11 +757,14 @@ class VAEEngine:
         # GEMMs share a grid).  C1V_BWD_PAIR=0 keeps the older form: dgrad chain on the main stream, wgrads on a side
         # stream (the captured graph keeps both branches; every cross-queue edge of it costs 5-10 us).
         stages = []           # (main ops, side ops, fused ops)
+        wg_items = []         # the weight-gradient problems of all stages (c1v_wgrad_batch)
 
         def stage(dgrad, wgrad, before=(), after=()):
             """dgrad / wgrad: (entry point, args) or None; before / after: extra ops (side / main in the two-stream form)."""
             main = ([op(*dgrad)] if dgrad else []) + list(after)
             side = list(before) + ([op(*wgrad)] if wgrad else [])
+            if wgrad:
+                wg_items.append(wgrad[1])
             if dgrad and wgrad and getattr(wgrad[1], 'tap_group', 0) >= 2:
                 # a fused-tap wgrad fills the chip by itself and runs one 232-register workgroup per CU: own launch
                 fused = side + main
@@ -874,6 +877,23 @@ class VAEEngine:
             stage(dg, wg, before=pre)
         self.bwd_stages = stages
         self.side_stream = torch.cuda.Stream(self.dev)
+        # Small batches: the chain of data gradients as launches of their own, then ALL weight gradients in one launch
+        # (c1v_wgrad_batch).  At C2 a dgrad alone takes 7-9 us and a paired dgrad + wgrad launch 9-15 (the wgrad workgroups,
+        # a few dozen with the longer K loops, are each pair's long pole) and no wgrad feeds the chain: backward 57 -> 46 us.
+        # Taken when all of them together are about one round of the chip's 2 x 256 workgroup slots (C1V_WGRAD_BATCH=0 / 1:
+        # never / whenever there are at most 12); larger batches keep the pairs, whose dgrad tiles fill the CUs the wgrad
+        # workgroups leave idle.  One rank only: the data-parallel step finalizes its first gradient bucket mid-backward.
+        self.bwd_batch = None
+        env_b = os.environ.get('C1V_WGRAD_BATCH', 'auto')
+        wg_wgs = sum((-(-a.I // 128)) * (-(-a.J // 128)) * a.taps * a.splits for a in wg_items)
+        if (env_b != '0' and not bn and self.world == 1 and not self.force_bucketed and 1 <= len(wg_items) <= L.WGRAD_BATCH_MAX and
+                all(getattr(a, 'tap_group', 0) < 2 for a in wg_items) and
+                (env_b == '1' or wg_wgs <= int(os.environ.get('C1V_WGRAD_BATCH_MAX_WGS', '640')))):
+            # (longest reductions first: they are the launch's long pole wherever they start)
+            order = sorted(wg_items, key=lambda a: -((a.r_end - a.r_begin) // max(1, a.splits)))
+            ba = L.WgradBatchArgs(len(order), (C.POINTER(L.WgradArgs) * L.WGRAD_BATCH_MAX)(*[C.pointer(a) for a in order]))
+            self._keep += order
+            self.bwd_batch = op('c1v_wgrad_batch', ba)
 
         # ---- optimizer
         f_fin = self.lib.c1v_grad_finalize
@@ -1008,6 +1028,11 @@ class VAEEngine:
         out = []
         for o in ops:
             if getattr(o, '__func__', None) is VAEEngine._run_backward:
+                if self.bwd_batch is not None:
+                    for main_ops, _, _ in self.bwd_stages:
+                        out.extend(main_ops)
+                    out.append(self.bwd_batch)
+                    continue
                 if not (os.environ.get('C1V_BWD_PAIR', '1') == '1' or self.g.use_batch_norm):
                     return None
                 for _, _, fused_ops in self.bwd_stages:
@@ -1121,6 +1146,11 @@ class VAEEngine:
     def _run_backward(self, lo: int = 0, hi: Optional[int] = None):
         """Stages [lo, hi) of backward: one paired dgrad + wgrad launch per stage (default), or the dgrad chain on the
         current stream with the wgrads (and the loss scalars) on the side stream, joined at the end."""
+        if self.bwd_batch is not None and lo == 0 and hi is None:
+            for main_ops, _, _ in self.bwd_stages:
+                self._run(main_ops)
+            self.bwd_batch()
+            return
         if os.environ.get('C1V_BWD_PAIR', '1') == '1' or self.g.use_batch_norm:
             for _, _, fused_ops in self.bwd_stages[lo:hi]:
                 self._run(fused_ops)

@@ -446,6 +446,15 @@ typedef struct c1v_vocab_argmax_noalloc_args {
 } c1v_vocab_argmax_noalloc_args;
 int c1v_vocab_argmax_noalloc(const c1v_vocab_argmax_noalloc_args*, void* stream);
 
+/* Up to C1V_WGRAD_BATCH_MAX weight gradients (conv / deconv / dense, tap_group 0, one operand type) in ONE launch.  For small
+ * batches (C2): every wgrad of the model is a few dozen workgroups and as long as its longest one, none of them feeds the
+ * chain of data gradients, so the backward pass becomes that chain (dgrad launches alone are 7-9 us where the paired
+ * dgrad + wgrad launches were 9-15) plus one launch for all weight gradients.  Results are those of the single launches,
+ * bit for bit.  No counterpart in the reference. */
+#define C1V_WGRAD_BATCH_MAX 12
+typedef struct c1v_wgrad_batch_args { int32_t n; const c1v_wgrad_args* items[C1V_WGRAD_BATCH_MAX]; } c1v_wgrad_batch_args;
+int c1v_wgrad_batch(const c1v_wgrad_batch_args*, void* stream);
+
 /* A recorded step: calls fns[i](args[i], stream) for i = 0 .. n-1 and stops at the first non-zero return code (which it
  * returns).  Every entry point above of the form `int f(const X_args*, void* stream)` can be listed.  Why: a training step at
  * C2 is 16 launches of 5-50 us; issued one by one from Python the host is the bottleneck, replayed as a HIP graph the runtime

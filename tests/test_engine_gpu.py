@@ -377,6 +377,33 @@ def test_xcd_aware_deal_of_the_paired_wgrad_workgroups_is_bit_identical(name, dt
         np.testing.assert_array_equal(got['1'][0][k_], v, err_msg=k_)
 
 
+@pytest.mark.parametrize('name', ['tiny1', 'deep3', 'k4', 'k2', 'mid', 'wide', 'kp384', 'longflat'])
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_all_weight_gradients_in_one_launch_are_bit_identical(name, dtype, monkeypatch):
+    """c1v_wgrad_batch (small batches: the chain of data gradients as launches of their own, then every weight gradient of
+    the model in ONE launch) against one paired dgrad + wgrad launch per layer: the same tiles and the same sums, so loss
+    and gradients agree to the bit -- as single ops and as a recorded step (three Nadam steps, parameters equal)."""
+    c = CASES[name]
+    og, params, Wv, x, ids, eps, mask_e, mask_d = make_case(c)
+    got = {}
+    for mode in ('1', '0'):
+        monkeypatch.setenv('C1V_WGRAD_BATCH', mode)
+        eng = build_engine(c, og, params, Wv, dtype)
+        assert (eng.bwd_batch is not None) == (mode == '1')
+        load_fixed(eng, x, ids, eps, mask_e, mask_d)
+        eng._run(eng.train_ops(False))
+        torch.cuda.synchronize()
+        grads, loss = eng.get_grads(), eng.loss()
+        for _ in range(3):
+            eng.train_step(use_graph=True, fixed_rng=True)
+        torch.cuda.synchronize()
+        got[mode] = (grads, loss, eng.params.cpu().numpy().copy())
+    assert got['1'][1] == got['0'][1]
+    for k_, v in got['0'][0].items():
+        np.testing.assert_array_equal(got['1'][0][k_], v, err_msg=k_)
+    np.testing.assert_array_equal(got['1'][2], got['0'][2])
+
+
 @pytest.mark.parametrize('name', ['mid', 'deep3'])
 def test_loss_scalars_with_the_per_sample_means_in_their_own_launch(name, monkeypatch):
     """Large batches (>= 65 536 target rows) sum the per-step losses of a sample in c1v_loss_sample_means (one wave per
