@@ -687,7 +687,22 @@ class VAEEngine:
             fblk[0] += (count + L.CHUNK - 1) // L.CHUNK
             return t
 
-        wgrad_rows = int(os.environ.get('C1V_WGRAD_ROWS', '384'))      # sample rows per wgrad split (measured at C2: 384 < 512 < 768)
+        # sample rows per wgrad split.  Paired launches (measured at C2 in round 2): 384 < 512 < 768.  With all weight gradients
+        # in one launch (c1v_wgrad_batch, below) fewer, longer workgroups are better -- two of them share a CU's ingest, and
+        # every split is a slab for grad_finalize to sum: C2 step 0.1877 ms at 384 and 512, 0.1849 at 768.  Whether a model
+        # takes the batched form is decided here, from the workgroups its weight gradients would have at that split size.
+        t128 = lambda n: -(-n // 128)
+        conv_layers = [(B * self.Xf.pitch, g.dec_filters[-1], self.V)] + \
+            [(B * self.Xd[i].pitch, g.width if i == 0 else g.dec_filters[i - 1], g.dec_filters[i]) for i in range(nd)] + \
+            [(B * self.Xe[l].pitch, g.input_vector_size if l == 0 else g.n_filters[l - 1], g.n_filters[l]) for l in range(nl)]
+        rows_batched = int(os.environ.get('C1V_WGRAD_ROWS_BATCHED', '768'))
+        est_wgs = sum(t128(ci) * t128(f) * k * max(1, rows // rows_batched) for rows, ci, f in conv_layers) + \
+            t128(self.D) * t128(self.nd) + t128(self.flat) * t128(2 * self.D)
+        env_b = os.environ.get('C1V_WGRAD_BATCH', 'auto')
+        self.batch_wgrads = (env_b != '0' and not bn and self.world == 1 and not self.force_bucketed and
+                             len(conv_layers) + 2 <= L.WGRAD_BATCH_MAX and os.environ.get('C1V_WGRAD_FUSE', '') == '' and
+                             (env_b == '1' or est_wgs <= int(os.environ.get('C1V_WGRAD_BATCH_MAX_WGS', '640'))))
+        wgrad_rows = int(os.environ.get('C1V_WGRAD_ROWS', str(rows_batched) if self.batch_wgrads else '384'))
 
         # Splits of the row (reduction) dimension of a conv wgrad.  Every split is one workgroup per (128 x 128 tile, tap) and
         # one slab for c1v_grad_finalize to sum.  Small batches: as many as keep `wgrad_rows` rows per split.  Large batches
@@ -884,11 +899,8 @@ class VAEEngine:
         # never / whenever there are at most 12); larger batches keep the pairs, whose dgrad tiles fill the CUs the wgrad
         # workgroups leave idle.  One rank only: the data-parallel step finalizes its first gradient bucket mid-backward.
         self.bwd_batch = None
-        env_b = os.environ.get('C1V_WGRAD_BATCH', 'auto')
-        wg_wgs = sum((-(-a.I // 128)) * (-(-a.J // 128)) * a.taps * a.splits for a in wg_items)
-        if (env_b != '0' and not bn and self.world == 1 and not self.force_bucketed and 1 <= len(wg_items) <= L.WGRAD_BATCH_MAX and
-                all(getattr(a, 'tap_group', 0) < 2 for a in wg_items) and
-                (env_b == '1' or wg_wgs <= int(os.environ.get('C1V_WGRAD_BATCH_MAX_WGS', '640')))):
+        if (self.batch_wgrads and 1 <= len(wg_items) <= L.WGRAD_BATCH_MAX and
+                all(getattr(a, 'tap_group', 0) < 2 for a in wg_items)):
             # (longest reductions first: they are the launch's long pole wherever they start)
             order = sorted(wg_items, key=lambda a: -((a.r_end - a.r_begin) // max(1, a.splits)))
             ba = L.WgradBatchArgs(len(order), (C.POINTER(L.WgradArgs) * L.WGRAD_BATCH_MAX)(*[C.pointer(a) for a in order]))
