@@ -136,6 +136,7 @@ class LossReduceArgs(C.Structure):
 
 
 WGRAD_BATCH_MAX = 12
+LIST_SIDE, LIST_FORK, LIST_JOIN = 1, 2, 4
 
 
 class WgradBatchArgs(C.Structure):
@@ -256,6 +257,7 @@ SYMBOLS = {
     'c1v_philox_multi': ([C.c_void_p, C.c_int32, C.c_int32, C.c_uint64, C.c_void_p, C.c_void_p], C.c_int),
     'c1v_step_prologue': ([_P(StepPrologueArgs), C.c_void_p], C.c_int),
     'c1v_run_list': ([C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p], C.c_int),
+    'c1v_run_list_fork': ([C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p], C.c_int),
     'c1v_last_error': ([], C.c_char_p),
     'c1v_version': ([], C.c_int),
     'c1v_device_info': ([C.c_int32, _P(C.c_int32)], C.c_int),

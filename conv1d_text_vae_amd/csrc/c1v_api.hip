@@ -210,3 +210,51 @@ extern "C" int c1v_run_list(int32_t n, const c1v_op_fn* fns, const void* const* 
     }
     return 0;
 }
+
+// The same with a second stream for work that is off the critical path (flags per entry: C1V_LIST_SIDE = issue on `side`;
+// C1V_LIST_FORK = that side entry first waits for everything issued on `stream` so far; C1V_LIST_JOIN = that main entry first
+// waits for everything issued on `side`).  If side work is still unjoined after the last entry, `stream` waits for it, so a
+// list is always complete on `stream`.  Events: two per host thread and device, created on first use, never timed.
+extern "C" int c1v_run_list_fork(int32_t n, const c1v_op_fn* fns, const void* const* args, const int32_t* flags, void* stream, void* side) {
+    C1V_REQUIRE(n >= 0 && (n == 0 || (fns && args && flags)) && side && side != stream, "run_list_fork: bad argument");
+    static thread_local hipEvent_t ev[16][2];
+    static thread_local bool have[16];
+    int dev = 0;
+    C1V_REQUIRE(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 16, "run_list_fork: no current device");
+    if (!have[dev]) {
+        for (int i = 0; i < 2; ++i) {
+            const hipError_t e = hipEventCreateWithFlags(&ev[dev][i], hipEventDisableTiming);
+            C1V_REQUIRE(e == hipSuccess, "run_list_fork: hipEventCreate: %s", hipGetErrorString(e));
+        }
+        have[dev] = true;
+    }
+    hipStream_t sm = (hipStream_t)stream, ss = (hipStream_t)side;
+    bool open_side = false;
+    auto join = [&]() -> int {
+        hipError_t e = hipEventRecord(ev[dev][1], ss);
+        if (e == hipSuccess) e = hipStreamWaitEvent(sm, ev[dev][1], 0);
+        C1V_REQUIRE(e == hipSuccess, "run_list_fork: join: %s", hipGetErrorString(e));
+        open_side = false;
+        return 0;
+    };
+    for (int32_t i = 0; i < n; ++i) {
+        C1V_REQUIRE(fns[i] != nullptr, "run_list_fork: entry %d has no function", i);
+        const int f = flags[i];
+        if (f & C1V_LIST_SIDE) {
+            if (f & C1V_LIST_FORK) {
+                hipError_t e = hipEventRecord(ev[dev][0], sm);
+                if (e == hipSuccess) e = hipStreamWaitEvent(ss, ev[dev][0], 0);
+                C1V_REQUIRE(e == hipSuccess, "run_list_fork: fork: %s", hipGetErrorString(e));
+            }
+            open_side = true;
+            const int rc = fns[i](args[i], side);
+            if (rc != 0) return rc;
+        } else {
+            if ((f & C1V_LIST_JOIN) && open_side && join()) return -1;
+            const int rc = fns[i](args[i], stream);
+            if (rc != 0) return rc;
+        }
+    }
+    if (open_side && join()) return -1;
+    return 0;
+}

@@ -899,6 +899,7 @@ class VAEEngine:
         # never / whenever there are at most 12); larger batches keep the pairs, whose dgrad tiles fill the CUs the wgrad
         # workgroups leave idle.  One rank only: the data-parallel step finalizes its first gradient bucket mid-backward.
         self.bwd_batch = None
+        self.bwd_overlap = 0
         if (self.batch_wgrads and 1 <= len(wg_items) <= L.WGRAD_BATCH_MAX and
                 all(getattr(a, 'tap_group', 0) < 2 for a in wg_items)):
             # (longest reductions first: they are the launch's long pole wherever they start)
@@ -906,6 +907,21 @@ class VAEEngine:
             ba = L.WgradBatchArgs(len(order), (C.POINTER(L.WgradArgs) * L.WGRAD_BATCH_MAX)(*[C.pointer(a) for a in order]))
             self._keep += order
             self.bwd_batch = op('c1v_wgrad_batch', ba)
+            # Measured and NOT taken (C1V_WGRAD_OVERLAP, default 0): weight gradients on a SECOND stream next to the chain of
+            # data gradients, whose launches leave most CUs idle (c1v_run_list_fork).  =1: the first stage's wgrad forks off
+            # (it only needs the loss gradient), the rest stays one batch behind the chain; =2: every stage's wgrad forks
+            # off behind the dgrad that produces its input.  Bit-identical, but every cross-stream edge costs more than
+            # it hides: C2 step 0.185 ms on one stream, 0.203 with one fork + join, 0.221 with four.
+            self.bwd_overlap = int(os.environ.get('C1V_WGRAD_OVERLAP', '0'))
+            firsts = [st_[1][-1] for st_ in stages if st_[1]]                       # the stages' own wgrad ops, in stage order
+            if self.bwd_overlap == 1 and len(order) >= 2 and stages[0][1]:
+                rest = [a for a in order if a is not wg_items[0]]
+                br = L.WgradBatchArgs(len(rest), (C.POINTER(L.WgradArgs) * L.WGRAD_BATCH_MAX)(*[C.pointer(a) for a in rest]))
+                self.bwd_batch_rest = op('c1v_wgrad_batch', br)
+            elif self.bwd_overlap == 2 and len(firsts) >= 2:
+                pass
+            else:
+                self.bwd_overlap = 0
 
         # ---- optimizer
         f_fin = self.lib.c1v_grad_finalize
@@ -1037,41 +1053,74 @@ class VAEEngine:
     def _flat(self, ops):
         """`ops` with the Python-level stage runner replaced by the launches it issues, or None if an op of the list cannot
         be recorded (the side-stream backward, ops that are not `f(args*, stream)` entry points)."""
-        out = []
+        out, flags = [], []
+        join_next = False
+
+        def put(o, f=0):
+            out.append(o)
+            flags.append(f)
         for o in ops:
             if getattr(o, '__func__', None) is VAEEngine._run_backward:
+                if self.bwd_batch is not None and self.bwd_overlap == 1:
+                    put(self.bwd_stages[0][1][-1], L.LIST_SIDE | L.LIST_FORK)
+                    for main_ops, _, _ in self.bwd_stages:
+                        for m_ in main_ops:
+                            put(m_)
+                    put(self.bwd_batch_rest)
+                    join_next = True
+                    continue
+                if self.bwd_batch is not None and self.bwd_overlap == 2:
+                    with_wg = [i for i, st_ in enumerate(self.bwd_stages) if st_[1]]
+                    for i, (main_ops, side_ops, _) in enumerate(self.bwd_stages):
+                        if side_ops and i != with_wg[-1]:
+                            put(side_ops[-1], L.LIST_SIDE | L.LIST_FORK)
+                        for m_ in main_ops:
+                            put(m_)
+                        if side_ops and i == with_wg[-1]:
+                            put(side_ops[-1])
+                    join_next = True
+                    continue
                 if self.bwd_batch is not None:
                     for main_ops, _, _ in self.bwd_stages:
-                        out.extend(main_ops)
-                    out.append(self.bwd_batch)
+                        for m_ in main_ops:
+                            put(m_)
+                    put(self.bwd_batch)
                     continue
                 if not (os.environ.get('C1V_BWD_PAIR', '1') == '1' or self.g.use_batch_norm):
                     return None
                 for _, _, fused_ops in self.bwd_stages:
-                    out.extend(fused_ops)
+                    for m_ in fused_ops:
+                        put(m_)
             elif getattr(o, '__name__', '') == 'mark_stale':
                 continue                                   # (the caller sets the flag, as for graph replays)
             else:
-                out.append(o)
+                put(o, L.LIST_JOIN if join_next else 0)
+                join_next = False
         self._list_blockers = [getattr(o, '__name__', repr(o)) for o in out if not hasattr(o, 'c_fn')]    # (diagnostic)
-        return out if not self._list_blockers else None
+        return (out, flags) if not self._list_blockers else None
 
     def _list(self, key: str, ops) -> bool:
         """Issue `ops` back to back from native code (c1v_run_list): one ctypes call for the whole step.  False if the list
         cannot be recorded."""
         rec = self._lists.get(key)
         if rec is None:
-            flat = self._flat(ops)
-            if flat is None:
+            fl = self._flat(ops)
+            if fl is None:
                 self._lists[key] = rec = False
             else:
+                flat, flags = fl
                 n = len(flat)
                 fns = (C.c_void_p * n)(*[C.cast(o.c_fn, C.c_void_p) for o in flat])
                 args = (C.c_void_p * n)(*[C.cast(C.pointer(o.c_args), C.c_void_p) for o in flat])
-                self._lists[key] = rec = (n, fns, args, flat)
+                fa = (C.c_int32 * n)(*flags) if any(flags) else None
+                self._lists[key] = rec = (n, fns, args, flat, fa)
         if rec is False:
             return False
-        rc = self.lib.c1v_run_list(rec[0], rec[1], rec[2], self._stream())
+        if rec[4] is not None:
+            rc = self.lib.c1v_run_list_fork(rec[0], rec[1], rec[2], rec[4], self._stream(),
+                                            C.c_void_p(self.side_stream.cuda_stream))
+        else:
+            rc = self.lib.c1v_run_list(rec[0], rec[1], rec[2], self._stream())
         if rc != 0:
             L.check(rc, 'c1v_run_list')
         return True

@@ -462,6 +462,16 @@ int c1v_wgrad_batch(const c1v_wgrad_batch_args*, void* stream);
  * there is no gap.  No counterpart in the reference (Keras' session.run plays this role there). */
 typedef int (*c1v_op_fn)(const void* args, void* stream);
 int c1v_run_list(int32_t n, const c1v_op_fn* fns, const void* const* args, void* stream);
+/* ... with a second stream for entries that are off the critical path (the weight gradients of a small-batch step run
+ * next to the chain of data gradients, which leaves most CUs idle).  flags[i]: C1V_LIST_SIDE = issue entry i on `side`;
+ * C1V_LIST_FORK = (side entry) it first waits for everything issued on `stream` so far; C1V_LIST_JOIN = (main entry) it
+ * first waits for everything issued on `side`.  Unjoined side work is joined after the last entry: when the call returns,
+ * everything it issued is ordered on `stream`.  Not for use under stream capture.  Measured at C2: every cross-stream edge
+ * costs ~9 us, more than the overlap hides, so the engine does not use it by default (C1V_WGRAD_OVERLAP). */
+#define C1V_LIST_SIDE 1
+#define C1V_LIST_FORK 2
+#define C1V_LIST_JOIN 4
+int c1v_run_list_fork(int32_t n, const c1v_op_fn* fns, const void* const* args, const int32_t* flags, void* stream, void* side);
 /* merge per-shard results gathered from R ranks: ties -> lowest global index */
 int c1v_argmax_merge(const float* scores /*[R][M]*/, const int32_t* idxs, int32_t R, int32_t M, float* score, int32_t* idx, void* stream);
 

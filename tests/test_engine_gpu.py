@@ -387,10 +387,13 @@ def test_all_weight_gradients_in_one_launch_are_bit_identical(name, dtype, monke
     og, params, Wv, x, ids, eps, mask_e, mask_d = make_case(c)
     got = {}
     monkeypatch.setenv('C1V_WGRAD_ROWS', '384')            # (the same row splits both ways: the batched form defaults to longer ones)
-    for mode in ('1', '0'):
-        monkeypatch.setenv('C1V_WGRAD_BATCH', mode)
+    # batched with the first wgrad / every wgrad but the last forked to the second stream (c1v_run_list_fork), batched on one
+    # stream, and the pairs
+    for mode in ('1', '1/2', '1/0', '0'):
+        monkeypatch.setenv('C1V_WGRAD_BATCH', mode[0])
+        monkeypatch.setenv('C1V_WGRAD_OVERLAP', mode[2:] or '1')      # ('1': first wgrad forked; the product default is 0)
         eng = build_engine(c, og, params, Wv, dtype)
-        assert (eng.bwd_batch is not None) == (mode == '1')
+        assert (eng.bwd_batch is not None) == (mode[0] == '1')
         load_fixed(eng, x, ids, eps, mask_e, mask_d)
         eng._run(eng.train_ops(False))
         torch.cuda.synchronize()
@@ -399,10 +402,11 @@ def test_all_weight_gradients_in_one_launch_are_bit_identical(name, dtype, monke
             eng.train_step(use_graph=True, fixed_rng=True)
         torch.cuda.synchronize()
         got[mode] = (grads, loss, eng.params.cpu().numpy().copy())
-    assert got['1'][1] == got['0'][1]
-    for k_, v in got['0'][0].items():
-        np.testing.assert_array_equal(got['1'][0][k_], v, err_msg=k_)
-    np.testing.assert_array_equal(got['1'][2], got['0'][2])
+    for mode in ('1', '1/2', '1/0'):
+        assert got[mode][1] == got['0'][1]
+        for k_, v in got['0'][0].items():
+            np.testing.assert_array_equal(got[mode][0][k_], v, err_msg=k_)
+        np.testing.assert_array_equal(got[mode][2], got['0'][2], err_msg=mode)
 
 
 @pytest.mark.parametrize('name', ['mid', 'deep3'])

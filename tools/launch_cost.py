@@ -7,7 +7,7 @@ eng, g, W, ids = bench.make_train_engine(bench.CONFIGS['c2'], 'bf16', torch.devi
 for _ in range(3):
     eng.train_step(from_ids=True)
 torch.cuda.synchronize()
-flat = eng._flat(eng.train_ops(True, True, True) + eng.update_ops())
+flat = eng._flat(eng.train_ops(True, True, True) + eng.update_ops())[0]
 names = ['prologue', 'enc', 'heads', 'latent', 'dense', 'deconv', 'out', 'stream', 'finish', 'bwd_out', 'bwd_deconv', 'bwd_dense', 'bwd_heads', 'bwd_enc', 'finalize', 'nadam']
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 for nm, o in zip(names, flat):
