@@ -49,7 +49,7 @@ struct TnMulti {
     int first[C1V_TN_MULTI_MAX + 1], gi[C1V_TN_MULTI_MAX], gij[C1V_TN_MULTI_MAX];
     TnParams p[C1V_TN_MULTI_MAX];
 };
-template <typename T>
+template <typename T, int NS>
 __global__ __launch_bounds__(C1V_GEMM_THREADS) void gemm_tn_multi_kernel(const TnMulti m) {
     const int id = blockIdx.x;
     int k = 0;
@@ -60,7 +60,7 @@ __global__ __launch_bounds__(C1V_GEMM_THREADS) void gemm_tn_multi_kernel(const T
     const int local = id - m.first[k], gi = m.gi[k], gij = m.gij[k];
     const int bz = local / gij, r = local - bz * gij;
     const int by = r / gi, bx = r - by * gi;
-    tn_body<T>(m.p[k], bx, by, bz);
+    tn_body<T, NS>(m.p[k], bx, by, bz);
 }
 
 // Fused-tap wgrad: a linear grid, dealt to (tile, tap group, row split) so that the workgroups which read the SAME rows --
@@ -229,13 +229,16 @@ int c1v_launch_tn_multi(int dtype, const TnParams* ps, int n, hipStream_t st) {
         C1V_REQUIRE(blocks < (1ll << 30), "wgrad batch: too many tiles");
     }
     for (int k = n; k <= C1V_TN_MULTI_MAX; ++k) m.first[k] = (int)blocks;
-    if (dtype == C1V_F32) {
-        static bool once = (set_lds(gemm_tn_multi_kernel<float>, TN_LDS), true); (void)once;
-        hipLaunchKernelGGL((gemm_tn_multi_kernel<float>), dim3((unsigned)blocks), dim3(C1V_GEMM_THREADS), TN_LDS, st, m);
-    } else {
-        static bool once = (set_lds(gemm_tn_multi_kernel<bf16_raw>, TN_LDS), true); (void)once;
-        hipLaunchKernelGGL((gemm_tn_multi_kernel<bf16_raw>), dim3((unsigned)blocks), dim3(C1V_GEMM_THREADS), TN_LDS, st, m);
-    }
+    // at most one workgroup per CU: the deep ring (144 KiB, one workgroup per CU anyway); more: two per CU with the shallow one
+    const char* env = getenv("C1V_TN_MULTI_NS");
+    const bool deep = env ? env[0] == '4' : blocks <= 256;
+    constexpr int LDS_DEEP = 4 * 2 * TN_TILE;
+#define C1V_TN_MULTI(T_, NS_, LDS_) do { \
+        static bool once = (set_lds(gemm_tn_multi_kernel<T_, NS_>, LDS_), true); (void)once; \
+        hipLaunchKernelGGL((gemm_tn_multi_kernel<T_, NS_>), dim3((unsigned)blocks), dim3(C1V_GEMM_THREADS), LDS_, st, m); } while (0)
+    if (dtype == C1V_F32) { if (deep) C1V_TN_MULTI(float, 4, LDS_DEEP); else C1V_TN_MULTI(float, 2, TN_LDS); }
+    else { if (deep) C1V_TN_MULTI(bf16_raw, 4, LDS_DEEP); else C1V_TN_MULTI(bf16_raw, 2, TN_LDS); }
+#undef C1V_TN_MULTI
     C1V_LAUNCH_CHECK();
     return 0;
 }

@@ -1138,7 +1138,10 @@ template <> struct TnCfg<float>    { static constexpr int BR = 32, PITCH = 128 *
 constexpr int TN_TILE = 18 * 1024;
 constexpr int TN_NS = 2;
 
-template <typename T>
+// NS: depth of the operand ring.  2 (72 KiB, two workgroups per CU hide each other's request latency) everywhere but in the
+// batched launch of small problems, where a CU holds one workgroup and a K tile then takes one request round trip
+// (~2 k cycles for 512 cycles of MFMAs): 4 stages keep three tiles in flight.
+template <typename T, int NS = TN_NS>
 __device__ __forceinline__ void tn_body(const TnParams& p, const int bx, const int by, const int bz) {
     using Cfg = TnCfg<T>;
     constexpr int BR = Cfg::BR, PITCH = Cfg::PITCH;
@@ -1147,7 +1150,7 @@ __device__ __forceinline__ void tn_body(const TnParams& p, const int bx, const i
     constexpr int STAGE = 2 * TN_TILE;
     constexpr int NPIECE = BR * PITCH / 1024;         // LDS-DMA requests (1 KiB each) per tile image
     static_assert(BR * PITCH == 18 * 1024 && NPIECE * 64 == BR * CPR, "tile image is 18 KiB of whole requests");
-    static_assert((TN_NS - 2) * NPIECE <= 63, "vmcnt is a 6-bit counter");
+    static_assert((NS - 1) * NPIECE <= 63, "vmcnt is a 6-bit counter");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1182,18 +1185,22 @@ __device__ __forceinline__ void tn_body(const TnParams& p, const int bx, const i
         const char* base = feed_a ? abase : dbase;
         const int dst0 = feed_a ? 0 : TN_TILE;
         auto issue = [&](int kt) {
-            char* d = smem + (kt % TN_NS) * STAGE + dst0;
+            char* d = smem + (kt % NS) * STAGE + dst0;
             const char* t = base + (int64_t)kt * BR * ld_b;
 #pragma unroll
             for (int i = 0; i < NPIECE; ++i) glds16(t + off[i], d + i * 1024);
         };
 #pragma unroll
-        for (int s = 0; s < TN_NS - 1; ++s)
+        for (int s = 0; s < NS - 1; ++s)
             if (s < KT) issue(s);
         for (int kt = 0; kt < KT; ++kt) {
-            if (kt + TN_NS - 2 < KT) wait_vmcnt<(TN_NS - 2) * NPIECE>(); else wait_vmcnt<0>();
+            // issued so far: tiles < min(KT, kt + NS - 1); tile kt must have landed, the later ones may be in flight
+            const int fly = (kt + NS - 1 < KT ? kt + NS - 1 : KT) - (kt + 1);
+            if (NS >= 4 && fly >= 2) wait_vmcnt<(NS >= 4 ? 2 : 0) * NPIECE>();
+            else if (NS >= 3 && fly >= 1) wait_vmcnt<(NS >= 3 ? 1 : 0) * NPIECE>();
+            else wait_vmcnt<0>();
             block_barrier();
-            if (kt + TN_NS - 1 < KT) issue(kt + TN_NS - 1);
+            if (kt + NS - 1 < KT) issue(kt + NS - 1);
         }
         block_barrier(); block_barrier(); block_barrier();     // the barriers of the epilogue below
         return;
@@ -1211,7 +1218,7 @@ __device__ __forceinline__ void tn_body(const TnParams& p, const int bx, const i
 
     for (int kt = 0; kt < KT; ++kt) {
         block_barrier();
-        const char* sa = smem + (kt % TN_NS) * STAGE;
+        const char* sa = smem + (kt % NS) * STAGE;
         const char* sd = sa + TN_TILE;
         if constexpr (sizeof(T) == 2) {
             const int g = lane >> 4, q = (lane & 15) >> 2, pq = lane & 3;

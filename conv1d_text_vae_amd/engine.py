@@ -689,15 +689,22 @@ class VAEEngine:
 
         # sample rows per wgrad split.  Paired launches (measured at C2 in round 2): 384 < 512 < 768.  With all weight gradients
         # in one launch (c1v_wgrad_batch, below) fewer, longer workgroups are better -- two of them share a CU's ingest, and
-        # every split is a slab for grad_finalize to sum: C2 step 0.1877 ms at 384 and 512, 0.1849 at 768.  Whether a model
+        # every split is a slab for grad_finalize to sum: C2 step 0.1877 ms at 384 and 512, 0.1849-0.1866 at 768.  Whether a model
         # takes the batched form is decided here, from the workgroups its weight gradients would have at that split size.
         t128 = lambda n: -(-n // 128)
         conv_layers = [(B * self.Xf.pitch, g.dec_filters[-1], self.V)] + \
             [(B * self.Xd[i].pitch, g.width if i == 0 else g.dec_filters[i - 1], g.dec_filters[i]) for i in range(nd)] + \
             [(B * self.Xe[l].pitch, g.input_vector_size if l == 0 else g.n_filters[l - 1], g.n_filters[l]) for l in range(nl)]
-        rows_batched = int(os.environ.get('C1V_WGRAD_ROWS_BATCHED', '768'))
-        est_wgs = sum(t128(ci) * t128(f) * k * max(1, rows // rows_batched) for rows, ci, f in conv_layers) + \
-            t128(self.D) * t128(self.nd) + t128(self.flat) * t128(2 * self.D)
+        def est(rps):
+            return sum(t128(ci) * t128(f) * k * max(1, rows // rps) for rows, ci, f in conv_layers) + \
+                t128(self.D) * t128(self.nd) + t128(self.flat) * t128(2 * self.D)
+        # (at most 256 workgroups = one per CU: the batched launch then takes the kernel with the four-stage operand ring, whose
+        # K tiles cost their MFMAs and not a request round trip each -- C2: 0.1834 ms at 1024 rows against 0.1854 at 768 with
+        # the two-stage ring and 294 workgroups; 768 rows with the deep ring would be two rounds: 0.1899)
+        rows_batched = int(os.environ.get('C1V_WGRAD_ROWS_BATCHED', '0'))
+        if rows_batched <= 0:
+            rows_batched = next((r_ for r_ in (768, 1024, 1536) if est(r_) <= 256), 768)
+        est_wgs = est(rows_batched)
         env_b = os.environ.get('C1V_WGRAD_BATCH', 'auto')
         self.batch_wgrads = (env_b != '0' and not bn and self.world == 1 and not self.force_bucketed and
                              len(conv_layers) + 2 <= L.WGRAD_BATCH_MAX and os.environ.get('C1V_WGRAD_FUSE', '') == '' and

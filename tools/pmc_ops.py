@@ -34,6 +34,12 @@ def op_list(eng, g):
     ops += list(zip(['l2norm', 'vocab_stream', 'xent_finish'][-len(core):], core))
     order = ['out_conv'] + ['deconv%d' % (i + 1) for i in reversed(range(nd))] + ['dec_dense', 'heads'] + \
         ['enc_conv%d' % (i + 1) for i in reversed(range(nl))]
+    if getattr(eng, 'bwd_batch', None) is not None:           # small batches: the dgrad chain, then all weight gradients in one launch
+        for n, (main, side, fused) in zip(order, eng.bwd_stages):
+            for i, o in enumerate(main):
+                ops.append((n + (' dgrad' if i == 0 else ' after%d' % i), o))
+        ops.append(('wgrad batch', eng.bwd_batch))
+        order = []
     for n, (main, side, fused) in zip(order, eng.bwd_stages):
         if len(fused) == 1:
             ops.append((n + ' bwd pair', fused[0]))
