@@ -458,7 +458,7 @@ int c1v_wgrad_batch(const c1v_wgrad_batch_args*, void* stream);
 /* A recorded step: calls fns[i](args[i], stream) for i = 0 .. n-1 and stops at the first non-zero return code (which it
  * returns).  Every entry point above of the form `int f(const X_args*, void* stream)` can be listed.  Why: a training step at
  * C2 is 16 launches of 5-50 us; issued one by one from Python the host is the bottleneck, replayed as a HIP graph the runtime
- * leaves ~8 us between two replays (4 % of the step, profiles/r03b_c2_trace_step_graph.txt), issued back to back from native code
+ * leaves ~8 us between two replays (4 % of the step, profiles/r03c_c2_trace_step_graph.txt), issued back to back from native code
  * there is no gap.  No counterpart in the reference (Keras' session.run plays this role there). */
 typedef int (*c1v_op_fn)(const void* args, void* stream);
 int c1v_run_list(int32_t n, const c1v_op_fn* fns, const void* const* args, void* stream);
