@@ -2,6 +2,7 @@
 // Nadam + global-norm clip, EOS truncation, Philox RNG.  All are grid-stride, coalesced, and reduction orders are
 // fixed (no float atomics) so that two runs of a step are bit-identical.
 #include "c1v_common.h"
+#include <stdlib.h>
 #include "c1v_lossred.h"
 
 // index of the descriptor that owns block `blk`: descriptors are sorted by first_block (the first one starts at 0).
@@ -729,7 +730,11 @@ struct PrologueDev {
 };
 __global__ __launch_bounds__(256) void step_prologue_kernel(const PrologueDev d) {
     int blk = (int)blockIdx.x;
-    if (blk < d.live_blocks) { live_rows_body(d.ids, d.M, d.items, d.vocab_tiles, d.max_splits, d.pos, d.ctl); return; }
+    if (blk < d.live_blocks) {
+        if (d.live_blocks > 1) live_rows_mb_body(d.ids, d.M, d.items, d.vocab_tiles, d.max_splits, d.pos, d.ctl, blk, d.live_blocks);
+        else live_rows_body(d.ids, d.M, d.items, d.vocab_tiles, d.max_splits, d.pos, d.ctl);
+        return;
+    }
     blk -= d.live_blocks;
     if (blk < d.sched_blocks) {                    // Nadam schedule scalars of this step's update (c1v_nadam_advance without the norm)
         if (threadIdx.x == 0) nadam_schedule(d.nadam_state, d.sched, -1.0f, nullptr, 0.9, 0.999, 0.004);
@@ -775,7 +780,12 @@ extern "C" int c1v_step_prologue(const c1v_step_prologue_args* a, void* stream) 
         const c1v_live_rows_args* l = a->live;
         C1V_REQUIRE(l->ids && l->pos && l->ctl && l->M > 0 && l->items > 0 && l->vocab_tiles > 0 && l->max_splits > 0, "step_prologue: bad live-row argument");
         C1V_REQUIRE(l->items >= (int)c1v_cdiv(l->M, VS_BM_ROWS), "step_prologue: the stream grid must cover all row tiles");
-        d.live_blocks = 1; d.ids = l->ids; d.M = l->M; d.items = l->items; d.vocab_tiles = l->vocab_tiles; d.max_splits = l->max_splits;
+        // (1 024 rows per 256-thread workgroup, up to LIVE_MB_MAX of them; larger tables stay with one workgroup's walk --
+        // and large batches build theirs in c1v_live_rows_gather anyway)
+        const char* env_mb = getenv("C1V_LIVE_MB");
+        const bool mb_off = env_mb && env_mb[0] == '0';
+        const int nb = (int)c1v_cdiv(l->M, 1024);
+        d.live_blocks = (nb <= LIVE_MB_MAX && !mb_off) ? nb : 1; d.ids = l->ids; d.M = l->M; d.items = l->items; d.vocab_tiles = l->vocab_tiles; d.max_splits = l->max_splits;
         d.pos = l->pos; d.ctl = l->ctl;
     }
     if (a->nadam_state) {

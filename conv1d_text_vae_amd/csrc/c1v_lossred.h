@@ -167,3 +167,72 @@ __device__ __forceinline__ void live_rows_body(const int* __restrict__ ids, int 
         ctl[0] = live; ctl[1] = tiles; ctl[2] = splits; ctl[3] = (vocab_tiles + splits - 1) / splits; ctl[4] = full;
     }
 }
+
+// The same table from SEVERAL workgroups of one launch, none waiting for another (small batches: the single workgroup above
+// walks 8 192 rows in 8 dependent 256-row steps per wave -- it was the longest job of the C2 step prologue).  Workgroup
+// `blk` of `nblk` owns rows [blk * R, (blk + 1) * R), R = 256 rows per wave: ONE scan step per wave.  What lies in front of
+// its range it counts itself (at most 15 R rows, read as 16-byte words, all requests in flight together) instead of
+// waiting for the workgroups before it; the last workgroup also writes the control block.  Same results as
+// live_rows_body, bit for bit (positions are integers).
+constexpr int LIVE_MB_MAX = 16;        // workgroups at most (beyond that the redundant counting outgrows what it saves)
+__device__ __forceinline__ void live_rows_mb_body(const int* __restrict__ ids, int M, int items, int vocab_tiles, int max_splits,
+                                                  int* __restrict__ pos, int* __restrict__ ctl, int blk, int nblk) {
+    __shared__ int wcnt[16], wbef[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x, nwave = nthr >> 6;
+    const int R = nwave * 256;
+    const int r0 = blk * R;
+    const bool vec = ((((uintptr_t)ids) | ((uintptr_t)pos)) & 15) == 0;
+    auto load4 = [&](int m) -> int4 {                                          // ids of rows m .. m+3 (-1 behind the end)
+        if (vec && m + 3 < M) return *(const int4*)(ids + m);
+        int4 v;
+        v.x = m < M ? ids[m] : -1; v.y = m + 1 < M ? ids[m + 1] : -1; v.z = m + 2 < M ? ids[m + 2] : -1; v.w = m + 3 < M ? ids[m + 3] : -1;
+        return v;
+    };
+    // this wave's step and the rows in front of the workgroup's range, requested together
+    const int m = r0 + wave * 256 + 4 * lane;
+    const int4 own = load4(m);
+    int before = 0;
+    for (int q0 = 4 * tid; q0 < r0; q0 += 4 * nthr * 4) {
+        int4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int q = q0 + u * 4 * nthr; v[u] = q < r0 ? load4(q) : make_int4(-1, -1, -1, -1); }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) before += (v[u].x >= 0) + (v[u].y >= 0) + (v[u].z >= 0) + (v[u].w >= 0);
+    }
+    const int c = (own.x >= 0) + (own.y >= 0) + (own.z >= 0) + (own.w >= 0);
+    int sc = c;                                        // inclusive scan of the step over the lanes
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(sc, o, 64); if (lane >= o) sc += t; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) before += __shfl_xor(before, o, 64);
+    if (lane == 63) wcnt[wave] = sc;                   // the step's total
+    if (lane == 0) wbef[wave] = before;                // this wave's share of the rows in front of the range
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < nwave; ++w) base += wbef[w];
+    for (int w = 0; w < wave; ++w) base += wcnt[w];
+    int p = base + sc - c;
+    int4 o4;
+    o4.x = own.x >= 0 ? p++ : -1; o4.y = own.y >= 0 ? p++ : -1; o4.z = own.z >= 0 ? p++ : -1; o4.w = own.w >= 0 ? p++ : -1;
+    if (vec && m + 3 < M) *(int4*)(pos + m) = o4;
+    else {
+        if (m < M) pos[m] = o4.x;
+        if (m + 1 < M) pos[m + 1] = o4.y;
+        if (m + 2 < M) pos[m + 2] = o4.z;
+        if (m + 3 < M) pos[m + 3] = o4.w;
+    }
+    if (blk == nblk - 1 && tid == nthr - 1) {
+        const int live = base + sc;                    // (last lane of the last wave: its inclusive scan ends the table)
+        const int tiles = (live + VS_BM_ROWS - 1) / VS_BM_ROWS;
+        int full = (tiles / VS_CUS) * VS_CUS;
+        if (full > items) full = (items / VS_CUS) * VS_CUS;
+        const int tail = tiles - full;
+        int splits = tail > 0 ? (full > 0 ? VS_CUS : items) / tail : 1;
+        if (tail > 0 && splits > (items - full) / tail) splits = (items - full) / tail;
+        if (splits > max_splits) splits = max_splits;
+        if (splits > vocab_tiles) splits = vocab_tiles;
+        if (splits < 1) splits = 1;
+        ctl[0] = live; ctl[1] = tiles; ctl[2] = splits; ctl[3] = (vocab_tiles + splits - 1) / splits; ctl[4] = full;
+    }
+}
+

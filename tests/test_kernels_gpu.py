@@ -292,3 +292,42 @@ def test_loss_curve_100_steps_within_one_percent():
         dev = np.max(np.abs(np.array(got) - np.array(ref)) / np.array(ref))
         print(dtype, 'max relative deviation of the loss curve over 100 steps: %.3e (loss %.3f -> %.3f)' % (dev, ref[0], ref[-1]))
         np.testing.assert_allclose(got, ref, rtol=1e-2, err_msg=dtype)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('M', [1025, 4100, 5000, 8192, 16384, 16385])
+def test_live_row_table_from_several_workgroups_matches_the_single_workgroup(M):
+    """The step prologue builds the live-row table with up to 16 workgroups of 1 024 rows, each counting the rows in front
+    of its range itself (live_rows_mb_body); c1v_live_rows builds it with one workgroup.  Positions and the control block
+    must be the same integers, and the positions those of a NumPy cumulative count -- ragged ends (M not a multiple of 4 or
+    of 1 024), all-dead and all-live stretches, and one size beyond the multi-workgroup limit (the prologue then falls back)."""
+    from conv1d_text_vae_amd import _lib as L
+    lib = L.load()
+    dev = torch.device('cuda:0')
+    rng = np.random.RandomState(M)
+    ids = rng.randint(-1, 5, size=M).astype(np.int32)
+    ids[ids > 0] = rng.randint(0, 1000, size=int((ids > 0).sum()))
+    ids[100:700] = -1
+    ids[2000:min(M, 3300)] = 7
+    t_ids = torch.from_numpy(ids).to(dev)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    items, vocab_tiles, max_splits = max(256, -(-M // 128)), 128, 16
+    res = []
+    for which in ('prologue', 'single'):
+        pos = torch.full((M + 8,), -7, dtype=torch.int32, device=dev)
+        ctl = torch.zeros(8, dtype=torch.int32, device=dev)
+        la = L.LiveRowsArgs(t_ids.data_ptr(), M, items, vocab_tiles, max_splits, pos.data_ptr(), ctl.data_ptr())
+        if which == 'prologue':
+            a = L.StepPrologueArgs()
+            a.live = C.pointer(la)
+            L.check(lib.c1v_step_prologue(C.byref(a), st), 'c1v_step_prologue')
+        else:
+            L.check(lib.c1v_live_rows(t_ids.data_ptr(), M, items, vocab_tiles, max_splits, pos.data_ptr(), ctl.data_ptr(), st), 'c1v_live_rows')
+        torch.cuda.synchronize()
+        res.append((pos.cpu().numpy(), ctl.cpu().numpy()))
+    np.testing.assert_array_equal(res[0][0], res[1][0])
+    np.testing.assert_array_equal(res[0][1], res[1][1])
+    live = ids >= 0
+    want = np.where(live, np.cumsum(live) - 1, -1).astype(np.int32)
+    np.testing.assert_array_equal(res[0][0][:M], want)
+    assert np.all(res[0][0][M:] == -7) and res[0][1][0] == int(live.sum())
