@@ -60,6 +60,12 @@ __global__ __launch_bounds__(C1V_GEMM_THREADS) void gemm_tn_multi_kernel(const T
     const int local = id - m.first[k], gi = m.gi[k], gij = m.gij[k];
     const int bz = local / gij, r = local - bz * gij;
     const int by = r / gi, bx = r - by * gi;
+    if constexpr (NS >= 4) {
+        // (the deep-ring form has the LDS for the fused-tap body as well; bz = tap group * splits + split there)
+        const int tg = __builtin_amdgcn_readfirstlane(m.p[k].tg);
+        if (tg == 3) { tn_taps_body<T, 3>(m.p[k], bx, by, bz); return; }
+        if (tg == 2) { tn_taps_body<T, 2>(m.p[k], bx, by, bz); return; }
+    }
     tn_body<T, NS>(m.p[k], bx, by, bz);
 }
 
@@ -218,21 +224,23 @@ int c1v_launch_tn_multi(int dtype, const TnParams* ps, int n, hipStream_t st) {
     TnMulti m{};
     m.n = n;
     int64_t blocks = 0;
+    bool fused = false;
     for (int k = 0; k < n; ++k) {
         if (c1v_check_tn(ps[k])) return -1;
-        C1V_REQUIRE(ps[k].tg == 0, "wgrad batch: fused-tap problems are launches of their own");
         m.p[k] = ps[k];
         m.gi[k] = (int)c1v_cdiv(ps[k].I, 128);
         m.gij[k] = m.gi[k] * (int)c1v_cdiv(ps[k].J, 128);
         m.first[k] = (int)blocks;
-        blocks += (int64_t)m.gij[k] * ps[k].taps * ps[k].splits;
+        const int groups = ps[k].tg >= 2 ? ps[k].taps / ps[k].tg : ps[k].taps;       // (tg divides taps: wgrad_params)
+        fused = fused || ps[k].tg >= 2;
+        blocks += (int64_t)m.gij[k] * groups * ps[k].splits;
         C1V_REQUIRE(blocks < (1ll << 30), "wgrad batch: too many tiles");
     }
     for (int k = n; k <= C1V_TN_MULTI_MAX; ++k) m.first[k] = (int)blocks;
     // at most one workgroup per CU: the deep ring (144 KiB, one workgroup per CU anyway); more: two per CU with the shallow one
     const char* env = getenv("C1V_TN_MULTI_NS");
-    const bool deep = env ? env[0] == '4' : blocks <= 256;
-    constexpr int LDS_DEEP = 4 * 2 * TN_TILE;
+    const bool deep = fused || (env ? env[0] == '4' : blocks <= 256);        // (fused-tap problems need the deep form's LDS)
+    constexpr int LDS_DEEP = 4 * 2 * TN_TILE > TNF_LDS ? 4 * 2 * TN_TILE : TNF_LDS;
 #define C1V_TN_MULTI(T_, NS_, LDS_) do { \
         static bool once = (set_lds(gemm_tn_multi_kernel<T_, NS_>, LDS_), true); (void)once; \
         hipLaunchKernelGGL((gemm_tn_multi_kernel<T_, NS_>), dim3((unsigned)blocks), dim3(C1V_GEMM_THREADS), LDS_, st, m); } while (0)

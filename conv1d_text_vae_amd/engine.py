@@ -705,6 +705,22 @@ class VAEEngine:
         if rows_batched <= 0:
             rows_batched = next((r_ for r_ in (768, 1024, 1536) if est(r_) <= 256), 768)
         est_wgs = est(rows_batched)
+        # Measured and NOT taken (C1V_WGRAD_BATCH_FUSE=1): inside such a one-workgroup-per-CU launch the taps of a
+        # convolution's weight gradient sharing a workgroup (tap_group: both operands fetched once for all taps, a third of
+        # the workgroups, so more and shorter row splits for the same 256 workgroups).  Bit-identical; at C2 the batched
+        # launch takes 28 us that way instead of 18 (step 0.193 ms against 0.181): the fused-tap body's K tile is 3 x the
+        # MFMAs behind one barrier, and with 5-8 K tiles per workgroup its longer fill and drain are not amortised.
+        tg_b = 3 if k % 3 == 0 else (2 if k % 2 == 0 else 0)
+        self.batch_fuse = 0
+        if est_wgs <= 256 and tg_b and os.environ.get('C1V_WGRAD_BATCH_FUSE', '0') == '1':
+            def est_f(rps):
+                return sum(t128(ci) * t128(f) * (k // tg_b) * max(1, rows // rps) for rows, ci, f in conv_layers) + \
+                    t128(self.D) * t128(self.nd) + t128(self.flat) * t128(2 * self.D)
+            rf = int(os.environ.get('C1V_WGRAD_ROWS_FUSED', '0'))
+            if rf <= 0:
+                rf = next((r_ for r_ in (320, 384, 512, 768, 1024) if est_f(r_) <= 256), 0)
+            if rf > 0:
+                self.batch_fuse, rows_batched, est_wgs = tg_b, rf, est_f(rf)
         env_b = os.environ.get('C1V_WGRAD_BATCH', 'auto')
         self.batch_wgrads = (env_b != '0' and not bn and self.world == 1 and not self.force_bucketed and
                              len(conv_layers) + 2 <= L.WGRAD_BATCH_MAX and os.environ.get('C1V_WGRAD_FUSE', '') == '' and
@@ -749,7 +765,10 @@ class VAEEngine:
                 groups = k // tgc if tgc else 0
                 if tgc and (fuse_env == '1' or (fuse_env == 'auto' and tiles * groups * (rows // wgrad_rows) >= 256)):
                     tg = tgc
-            if tg:
+            if self.batch_wgrads and self.batch_fuse and k > 1:
+                tg = self.batch_fuse
+                sp = int(max(1, min(rows // wgrad_rows, wgrad_max)))
+            elif tg:
                 # the workgroups of one row split go to one XCD (32 CUs, one workgroup each): whole splits per XCD
                 per_split = tiles * (k // tg)
                 sp = 8 * max(1, (fuse_wgs // 8) // per_split)
@@ -907,8 +926,7 @@ class VAEEngine:
         # workgroups leave idle.  One rank only: the data-parallel step finalizes its first gradient bucket mid-backward.
         self.bwd_batch = None
         self.bwd_overlap = 0
-        if (self.batch_wgrads and 1 <= len(wg_items) <= L.WGRAD_BATCH_MAX and
-                all(getattr(a, 'tap_group', 0) < 2 for a in wg_items)):
+        if self.batch_wgrads and 1 <= len(wg_items) <= L.WGRAD_BATCH_MAX:
             # (longest reductions first: they are the launch's long pole wherever they start)
             order = sorted(wg_items, key=lambda a: -((a.r_end - a.r_begin) // max(1, a.splits)))
             ba = L.WgradBatchArgs(len(order), (C.POINTER(L.WgradArgs) * L.WGRAD_BATCH_MAX)(*[C.pointer(a) for a in order]))

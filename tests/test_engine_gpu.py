@@ -389,9 +389,10 @@ def test_all_weight_gradients_in_one_launch_are_bit_identical(name, dtype, monke
     monkeypatch.setenv('C1V_WGRAD_ROWS', '384')            # (the same row splits both ways: the batched form defaults to longer ones)
     # batched with the first wgrad / every wgrad but the last forked to the second stream (c1v_run_list_fork), batched on one
     # stream, and the pairs
-    for mode in ('1', '1/2', '1/0', '0'):
+    for mode in ('1', '1/2', '1/0', '1/f', '0'):
         monkeypatch.setenv('C1V_WGRAD_BATCH', mode[0])
-        monkeypatch.setenv('C1V_WGRAD_OVERLAP', mode[2:] or '1')      # ('1': first wgrad forked; the product default is 0)
+        monkeypatch.setenv('C1V_WGRAD_OVERLAP', '0' if mode == '1/f' else (mode[2:] or '1'))    # ('1': first wgrad forked; the product default is 0)
+        monkeypatch.setenv('C1V_WGRAD_BATCH_FUSE', '1' if mode == '1/f' else '0')            # ('1/f': fused-tap problems inside the batch)
         eng = build_engine(c, og, params, Wv, dtype)
         assert (eng.bwd_batch is not None) == (mode[0] == '1')
         load_fixed(eng, x, ids, eps, mask_e, mask_d)
@@ -402,7 +403,7 @@ def test_all_weight_gradients_in_one_launch_are_bit_identical(name, dtype, monke
             eng.train_step(use_graph=True, fixed_rng=True)
         torch.cuda.synchronize()
         got[mode] = (grads, loss, eng.params.cpu().numpy().copy())
-    for mode in ('1', '1/2', '1/0'):
+    for mode in ('1', '1/2', '1/0', '1/f'):
         assert got[mode][1] == got['0'][1]
         for k_, v in got['0'][0].items():
             np.testing.assert_array_equal(got[mode][0][k_], v, err_msg=k_)
