@@ -97,6 +97,9 @@ extern "C" int c1v_debug_read(unsigned long long* dst, int n) {
 //   -DVS_PROLOGUE_OVERLAP=1  (round 3) the prologue's requests ordered tile 0 | Yhat | tile 1, a counted wait for tile 0 only and
 //                      the first tile peeled so that its MFMAs wait for Yhat k-step by k-step: parity-green, measured at C2
 //                      49.8 us against 48.8 (the first tile's barrier waits for everything half a tile later anyway)
+#ifndef VS_XCD_ROWS
+#define VS_XCD_ROWS 1
+#endif
 #ifndef VS_PROLOGUE_OVERLAP
 #define VS_PROLOGUE_OVERLAP 0
 #endif
@@ -153,7 +156,20 @@ void vocab_stream_kernel(const bf16_raw* __restrict__ yhat, int M, const bf16_ra
             bx = item; split = 0; tiles_per_split = tiles_total;
         } else {                                    // the remainder, cut into ctl[2] splits each
             const int r = item - full;
-            bx = r / splits; split = r - bx * splits; bx += full;
+#if VS_XCD_ROWS
+            // workgroups go to the XCDs round-robin (XCD = id % 8): the splits of ONE row tile on ONE XCD, so that its L2
+            // fetches the tile's 80 KiB of Yhat once for all of them (every workgroup of the launch loads its rows at the
+            // same time: the prologue runs at the ~11 B/clk a CU gets in such a burst).  Whole tiles per XCD first; the
+            // tiles that are left over take the left-over slots of all XCDs.
+            const int pool = (int)(gridDim.x * gridDim.y) - full;
+            const int xcd = r & 7, slot = r >> 3, spx = pool >> 3, tpx = spx / splits;
+            if ((pool & 7) == 0 && tpx > 0) {
+                if (slot < tpx * splits) { bx = (slot / splits) * 8 + xcd; split = slot % splits; }
+                else { const int lo = (slot - tpx * splits) * 8 + xcd; bx = 8 * tpx + lo / splits; split = lo % splits; }
+                bx += full;
+            } else
+#endif
+            { bx = r / splits; split = r - bx * splits; bx += full; }
             tiles_per_split = ctl[3];
         }
         if (bx * WG_ROWS >= live) return;           // whole workgroup, before any barrier
