@@ -244,13 +244,18 @@ def hbm_table(eng, g, B, ids, reps=20):
     if eng.fuse_norm:
         Xf = eng.Xf
         add('gemm_ntw_row_kernel (out_conv fwd + l2norm)', eng.ops_dec[-1],
-            B * Xf.pitch * Xf.cp * es + n_live * (Vp * 4 + kp * es + 4) + M * 4,
+            B * Xf.pitch * Xf.cp * es + n_live * (Vp * 4 + kp * es + 4) + M * 4 +
+            ((M - n_live) * dy.cp * es if getattr(eng, 'finish_compact', False) else 0),
             'decoder activations in (every buffer row once); fp32 y, yhat, rnorm of the live rows out -- a GEMM launch, listed '
             'here because its length is its stores')
     if len(core) == 3:
         add('l2norm_rows_kernel', core[0], n_live * (Vp * 4 + kp * es + 4), 'fp32 y of the live rows in; yhat, rnorm out')
-    add('xent_finish_kernel', core[-1], slab_rows * kp * ut_es + n_live * (2 * kp * es + V * 4 + 8) + M * 4 + M * dy.cp * es,
-        'U slabs, yhat, target rows of W, fp32 y (live rows) in; dy (all rows) out')
+    if getattr(eng, 'finish_compact', False):
+        add('xent_finish_kernel', core[-1], slab_rows * kp * ut_es + n_live * (2 * kp * es + V * 4 + 16) + n_live * dy.cp * es,
+            'U slabs, yhat, target rows of W, fp32 y in; dy out -- live rows only (the zero rows of dy come from the out conv)')
+    else:
+        add('xent_finish_kernel', core[-1], slab_rows * kp * ut_es + n_live * (2 * kp * es + V * 4 + 8) + M * 4 + M * dy.cp * es,
+            'U slabs, yhat, target rows of W, fp32 y (live rows) in; dy (all rows) out')
     if eng._input_own_launch():
         add('live_gather_kernel (live_rows + gather_input)', eng._live_gather_op(),
             M * 8 + B * g.input_text_size * 4 + n_in_live * eng.in_table.shape[1] * 4 + B * g.input_text_size * Xe.cp * es,

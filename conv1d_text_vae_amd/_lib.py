@@ -36,7 +36,7 @@ class Epilogue(C.Structure):
                 ('lat_mlv', C.c_void_p), ('lat_eps', C.c_void_p), ('lat_keep', C.c_void_p), ('lat_D', C.c_int32),
                 ('lat_keep_prob', C.c_float), ('lat_std_scale', C.c_float), ('lat_kc', C.c_float), ('bias_row_w', C.c_int32),
                 ('nrm_yhat', C.c_void_p), ('nrm_kp', C.c_int32), ('nrm_rnorm', C.c_void_p), ('nrm_qscale', C.c_float),
-                ('nrm_pos', C.c_void_p), ('nrm_live_only', C.c_int32)]
+                ('nrm_pos', C.c_void_p), ('nrm_live_only', C.c_int32), ('nrm_dy', Seq)]
 
 
 class ConvArgs(C.Structure):
@@ -121,7 +121,7 @@ class XentFinishArgs(C.Structure):
                 ('rnorm', C.c_void_p), ('qscale', C.c_float), ('ids', C.c_void_p), ('B', C.c_int32), ('T', C.c_int32),
                 ('V', C.c_int32), ('B_global', C.c_int32), ('xent_rows', C.c_void_p), ('xent_b', C.c_void_p),
                 ('dy', Seq), ('y', C.c_void_p), ('ldy', C.c_int64), ('pos', C.c_void_p), ('live_ctl', C.c_void_p),
-                ('ut_dtype', C.c_int32)]
+                ('ut_dtype', C.c_int32), ('live_rows', C.c_void_p), ('live_ids', C.c_void_p)]
 
 
 class SegDesc(C.Structure):
@@ -164,7 +164,7 @@ class RngDesc(C.Structure):
 
 class LiveRowsArgs(C.Structure):
     _fields_ = [('ids', C.c_void_p), ('M', C.c_int32), ('items', C.c_int32), ('vocab_tiles', C.c_int32),
-                ('max_splits', C.c_int32), ('pos', C.c_void_p), ('ctl', C.c_void_p)]
+                ('max_splits', C.c_int32), ('pos', C.c_void_p), ('ctl', C.c_void_p), ('rows', C.c_void_p), ('cids', C.c_void_p)]
 
 
 class StepPrologueArgs(C.Structure):
@@ -223,6 +223,7 @@ SYMBOLS = {
     'c1v_latent_head_bwd': ([_P(LatentArgs), C.c_void_p], C.c_int),
     'c1v_l2norm_rows': ([_P(L2NormArgs), C.c_void_p], C.c_int),
     'c1v_live_rows': ([C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p], C.c_int),
+    'c1v_live_rows_table': ([_P(LiveRowsArgs), C.c_void_p], C.c_int),
     'c1v_live_rows_gather': ([_P(LiveRowsArgs), _P(GatherInputArgs), C.c_void_p], C.c_int),
     'c1v_cos_softmax_accum': ([_P(XentAccumArgs), C.c_void_p], C.c_int),
     'c1v_cos_softmax_xent_fwd': ([_P(XentAccumArgs), C.c_void_p], C.c_int),

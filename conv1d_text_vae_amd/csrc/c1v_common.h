@@ -122,6 +122,7 @@ struct EpiDev {
     const float* lat_mlv; const float* lat_eps; const uint8_t* lat_keep; int lat_D; float lat_keep_prob, lat_std_scale, lat_kc;
     int bias_row_w;       // c1v_epilogue::bias_row_w
     void* nrm_yhat; int nrm_kp; float* nrm_rnorm; float nrm_qscale; const int* nrm_pos; int nrm_live_only; int nrm_T;   // C1V_ROW_NORM (nrm_T = compute dtype)
+    char* nrm_dy; int64_t nrm_dy_bstride_b; int nrm_dy_off, nrm_dy_row_b;      // rows without a target: zero row (b, u) of this buffer (byte strides)
     int fastw;            // 4 / 2: every group address of the epilogue is a multiple of that many elements (vector path); 0: element-wise
 };
 

@@ -738,15 +738,15 @@ struct PrologueDev {
     const c1v_rng_desc* rng_descs; int n_rng, rng_blocks; uint64_t seed; const uint64_t* ctr;
     int in_kind, in_dtype, in_blocks;            // 0 none, 1 pack, 2 gather
     const float* src; int64_t ld; const int* in_ids; int T, C; c1v_seq dst;
-    int live_blocks; const int* ids; int M, items, vocab_tiles, max_splits; int* pos; int* ctl;
+    int live_blocks; const int* ids; int M, items, vocab_tiles, max_splits; int* pos; int* ctl; int* live_rows; int* live_cids;
     int sched_blocks; double* nadam_state; float* sched;
     int pack_blocks; const c1v_pack_desc* pack_descs; int n_pack;
 };
 __global__ __launch_bounds__(256) void step_prologue_kernel(const PrologueDev d) {
     int blk = (int)blockIdx.x;
     if (blk < d.live_blocks) {
-        if (d.live_blocks > 1) live_rows_mb_body(d.ids, d.M, d.items, d.vocab_tiles, d.max_splits, d.pos, d.ctl, blk, d.live_blocks);
-        else live_rows_body(d.ids, d.M, d.items, d.vocab_tiles, d.max_splits, d.pos, d.ctl);
+        if (d.live_blocks > 1) live_rows_mb_body(d.ids, d.M, d.items, d.vocab_tiles, d.max_splits, d.pos, d.ctl, blk, d.live_blocks, d.live_rows, d.live_cids);
+        else live_rows_body(d.ids, d.M, d.items, d.vocab_tiles, d.max_splits, d.pos, d.ctl, d.live_rows, d.live_cids);
         return;
     }
     blk -= d.live_blocks;
@@ -801,6 +801,8 @@ extern "C" int c1v_step_prologue(const c1v_step_prologue_args* a, void* stream) 
         const int nb = (int)c1v_cdiv(l->M, 1024);
         d.live_blocks = (nb <= LIVE_MB_MAX && !mb_off) ? nb : 1; d.ids = l->ids; d.M = l->M; d.items = l->items; d.vocab_tiles = l->vocab_tiles; d.max_splits = l->max_splits;
         d.pos = l->pos; d.ctl = l->ctl;
+        C1V_REQUIRE((l->rows != nullptr) == (l->cids != nullptr), "step_prologue: live rows / cids come together");
+        d.live_rows = l->rows; d.live_cids = l->cids;
     }
     if (a->nadam_state) {
         C1V_REQUIRE(a->sched, "step_prologue: nadam_state needs sched");
@@ -827,11 +829,11 @@ extern "C" int c1v_philox_multi(const c1v_rng_desc* descs, int32_t n_desc, int32
 // Large batches (see VAEEngine._input_own_launch): the live-row table and the encoder operand in ONE launch of 1024-thread
 // blocks -- block 0 scans the targets with 16 waves, the others assemble the input; neither needs the other's result.
 struct LiveGatherDev {
-    const int* ids; int M, items, vocab_tiles, max_splits; int* pos; int* ctl;
+    const int* ids; int M, items, vocab_tiles, max_splits; int* pos; int* ctl; int* rows; int* cids;
     const float* table; int64_t ld; const int* in_ids; int T, C; c1v_seq dst; int in_blocks, in_dtype;
 };
 __global__ __launch_bounds__(1024) void live_gather_kernel(const LiveGatherDev d) {
-    if (blockIdx.x == 0) { live_rows_body(d.ids, d.M, d.items, d.vocab_tiles, d.max_splits, d.pos, d.ctl); return; }
+    if (blockIdx.x == 0) { live_rows_body(d.ids, d.M, d.items, d.vocab_tiles, d.max_splits, d.pos, d.ctl, d.rows, d.cids); return; }
     const int blk = (int)blockIdx.x - 1;
     if (d.in_dtype == C1V_F32) gather_input_body<float>(d.table, d.ld, d.in_ids, d.T, d.C, d.dst, blk, d.in_blocks);
     else gather_input_body<bf16_raw>(d.table, d.ld, d.in_ids, d.T, d.C, d.dst, blk, d.in_blocks);
@@ -846,6 +848,8 @@ extern "C" int c1v_live_rows_gather(const c1v_live_rows_args* l, const c1v_gathe
     C1V_REQUIRE(a->dst.cp % 8 == 0 && a->dst.bstride % 8 == 0 && ((uintptr_t)a->dst.data % 32) == 0, "live_rows_gather: dst rows must be 8-element groups, 32-byte aligned");
     LiveGatherDev d{};
     d.ids = l->ids; d.M = l->M; d.items = l->items; d.vocab_tiles = l->vocab_tiles; d.max_splits = l->max_splits; d.pos = l->pos; d.ctl = l->ctl;
+    C1V_REQUIRE((l->rows != nullptr) == (l->cids != nullptr), "live_rows_gather: live rows / cids come together");
+    d.rows = l->rows; d.cids = l->cids;
     d.table = a->table; d.ld = a->ld; d.in_ids = a->ids; d.T = a->T; d.C = a->C; d.dst = a->dst; d.in_dtype = a->dst.dtype;
     const int64_t total = (int64_t)a->dst.batch * a->T * (a->dst.cp / 8);
     int64_t nb = c1v_cdiv(total, 1024 * 4);                        // ~4 eight-element groups per thread

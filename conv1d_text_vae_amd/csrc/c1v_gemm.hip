@@ -270,6 +270,14 @@ int c1v_fill_epi(const c1v_epilogue& e, EpiDev& d, int M, int Le, int nrows, int
         C1V_REQUIRE(e.nrm_yhat && e.nrm_rnorm && e.nrm_kp >= N && e.nrm_kp % 8 == 0 && e.nrm_kp <= 320, "ROW_NORM: needs yhat, rnorm and n_out <= nrm_kp <= 320");
         C1V_REQUIRE(!e.relu && e.act.data == nullptr && e.keep == nullptr && e.sel == nullptr && e.reshape_w <= 0 && e.dst.dtype == C1V_F32,
                     "ROW_NORM: a plain fp32 STORE epilogue (bias only)");
+        d.nrm_dy = nullptr;
+        if (e.nrm_dy.data) {
+            const int es = c1v_esize(e.nrm_dy.dtype);
+            C1V_REQUIRE(e.nrm_pos && e.nrm_dy.len >= nrows && e.nrm_dy.batch * (int64_t)1 > 0 && (e.nrm_dy.cp * es) % 16 == 0 && e.nrm_dy.cp * es <= 1024 &&
+                        (e.nrm_dy.bstride * es) % 16 == 0 && ((uintptr_t)e.nrm_dy.data % 16) == 0,
+                        "ROW_NORM: nrm_dy needs nrm_pos and rows of whole 16-byte words, at most 1 KiB each");
+            d.nrm_dy = (char*)e.nrm_dy.data; d.nrm_dy_bstride_b = e.nrm_dy.bstride * es; d.nrm_dy_off = e.nrm_dy.off; d.nrm_dy_row_b = e.nrm_dy.cp * es;
+        }
         C1V_REQUIRE(e.dst.cp <= 320 && e.dst.cp % 4 == 0 && e.dst.bstride % 4 == 0 && ((uintptr_t)e.dst.data % 16) == 0 && ((uintptr_t)e.nrm_yhat % 16) == 0,
                     "ROW_NORM: rows of dst and yhat must be 16-byte aligned (cp %d)", e.dst.cp);
         d.fastw = 0;

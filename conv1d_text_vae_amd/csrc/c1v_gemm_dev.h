@@ -1039,6 +1039,14 @@ __device__ __forceinline__ void ntw_body(const NtParams& p, const int bx, const 
                                        (uint32_t)__builtin_amdgcn_readlane((int)my_y, l);
                     const float4 a4 = va[k4], b4 = vb[k4];
                     // (pos == -2: not a row of the convolution -- between samples / past the end)
+                    if (pos == -1 && ev.nrm_dy != nullptr) {
+                        // a row without a target: its loss gradient is zero, written here so that the finish step can run
+                        // over the live rows only
+                        const int b_ = __builtin_amdgcn_readlane(my_b, l), u_ = __builtin_amdgcn_readlane(my_u, l);
+                        if (16 * lane < ev.nrm_dy_row_b)
+                            *(uint4*)(ev.nrm_dy + (int64_t)b_ * ev.nrm_dy_bstride_b + (int64_t)(ev.nrm_dy_off + u_) * ev.nrm_dy_row_b + 16 * lane) =
+                                make_uint4(0u, 0u, 0u, 0u);
+                    }
                     if (pos >= 0 || (pos == -1 && !ev.nrm_live_only)) {
                         float* yr = ydst + yo + 4 * lane;
                         if (4 * lane < ev.dst_cp) *(float4*)yr = a4;

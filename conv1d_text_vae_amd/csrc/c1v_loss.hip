@@ -62,8 +62,8 @@ __global__ __launch_bounds__(256) void l2norm_rows_kernel(const float* __restric
 }
 
 __global__ __launch_bounds__(1024) void live_rows_kernel(const int* __restrict__ ids, int M, int items, int vocab_tiles, int max_splits,
-                                                         int* __restrict__ pos, int* __restrict__ ctl) {
-    live_rows_body(ids, M, items, vocab_tiles, max_splits, pos, ctl);
+                                                         int* __restrict__ pos, int* __restrict__ ctl, int* __restrict__ rows, int* __restrict__ cids) {
+    live_rows_body(ids, M, items, vocab_tiles, max_splits, pos, ctl, rows, cids);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -668,8 +668,9 @@ template <bool UB> __device__ __forceinline__ float ut_f(const float* ut, int64_
 #define C1V_FINISH_PARAMS const float* __restrict__ ut, int splits, int kp, int m_pad, int ones_col, const T* __restrict__ yhat, \
     const T* __restrict__ w, const float* __restrict__ rnorm, float qscale, const int* __restrict__ ids, int B, int T_len, int V, \
     int B_global, float* __restrict__ xent_rows, c1v_seq dy, const float* __restrict__ y, int64_t ldy, const int* __restrict__ pos, \
-    const int* __restrict__ ctl
-#define C1V_FINISH_ARGS ut, splits, kp, m_pad, ones_col, yhat, w, rnorm, qscale, ids, B, T_len, V, B_global, xent_rows, dy, y, ldy, pos, ctl
+    const int* __restrict__ ctl, const int* __restrict__ live_rows, const int* __restrict__ live_ids
+#define C1V_FINISH_ARGS ut, splits, kp, m_pad, ones_col, yhat, w, rnorm, qscale, ids, B, T_len, V, B_global, xent_rows, dy, y, ldy, pos, ctl, \
+    live_rows, live_ids
 template <typename T, bool UB>
 __device__ __forceinline__ void xent_finish_body(C1V_FINISH_PARAMS) {
     // one wave per sample row; everything is row-wise and coalesced.  The projection that backpropagates through the
@@ -677,14 +678,24 @@ __device__ __forceinline__ void xent_finish_body(C1V_FINISH_PARAMS) {
     // which the transposed final conv amplifies coherently (measured: 6x larger relative error downstream).
     const int lane = threadIdx.x & 63;
     const int M = B * T_len;
-    const int m = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (m >= M) return;
+    int m = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int id, cr;
+    if (live_rows) {
+        // one wave per LIVE row (the grid still covers M rows: a captured launch cannot resize it; waves behind the last
+        // live row leave at once): compact row -> sample row and target from the inverse table of c1v_live_rows
+        cr = m;
+        if (cr >= __builtin_amdgcn_readfirstlane(ctl[0])) return;
+        m = __builtin_amdgcn_readfirstlane(live_rows[cr]);
+        id = __builtin_amdgcn_readfirstlane(live_ids[cr]);
+    } else {
+        if (m >= M) return;
+        id = ids[m];
+        // live-row compaction: `cr` is the row of yhat / ut that belongs to sample row m; rows without a target have none
+        // (wave-uniform values are moved to scalar registers so that the loops over the slabs stay scalar loops)
+        cr = pos ? __builtin_amdgcn_readfirstlane(pos[m]) : m;
+    }
     const int b = m / T_len, t = m - b * T_len;
-    const int id = ids[m];
     const bool mask = id >= 0;
-    // live-row compaction: `cr` is the row of yhat / ut that belongs to sample row m; rows without a target have none
-    // (wave-uniform values are moved to scalar registers so that the loops over the slabs stay scalar loops)
-    const int cr = pos ? __builtin_amdgcn_readfirstlane(pos[m]) : m;
     if (ctl) splits = __builtin_amdgcn_readfirstlane((cr >> 7) < ctl[4] ? 1 : ctl[2]);    // (the full row tiles have ONE slab)
     if (cr < 0) {                                   // wave-uniform: no loss term, zero gradient
         if (lane == 0) xent_rows[m] = 0.0f;
@@ -958,7 +969,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8)))
 void xent_finish_bf16_kernel(const float* __restrict__ ut, int splits, int kp, int m_pad, int ones_col, const bf16_raw* __restrict__ yhat,
                              const bf16_raw* __restrict__ w, const float* __restrict__ rnorm, float qscale, const int* __restrict__ ids, int B,
                              int T_len, int V, int B_global, float* __restrict__ xent_rows, c1v_seq dy, const float* __restrict__ y, int64_t ldy,
-                             const int* __restrict__ pos, const int* __restrict__ ctl) {
+                             const int* __restrict__ pos, const int* __restrict__ ctl, const int* __restrict__ live_rows,
+                             const int* __restrict__ live_ids) {
     xent_finish_body<bf16_raw, true>(C1V_FINISH_ARGS);
 }
 
@@ -1170,7 +1182,17 @@ extern "C" int c1v_live_rows(const int32_t* ids, int32_t M, int32_t items, int32
                              void* stream) {
     C1V_REQUIRE(ids && pos && ctl && M > 0 && items > 0 && vocab_tiles > 0 && max_splits > 0, "live_rows: bad argument");
     C1V_REQUIRE(items >= (int)c1v_cdiv(M, VS_BM), "live_rows: the stream grid (%d workgroups) must cover all %d row tiles", items, (int)c1v_cdiv(M, VS_BM));
-    hipLaunchKernelGGL(live_rows_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, ids, M, items, vocab_tiles, max_splits, pos, ctl);
+    hipLaunchKernelGGL(live_rows_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, ids, M, items, vocab_tiles, max_splits, pos, ctl,
+                       (int*)nullptr, (int*)nullptr);
+    C1V_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int c1v_live_rows_table(const c1v_live_rows_args* a, void* stream) {
+    C1V_REQUIRE(a && a->ids && a->pos && a->ctl && a->M > 0 && a->items > 0 && a->vocab_tiles > 0 && a->max_splits > 0, "live_rows_table: bad argument");
+    C1V_REQUIRE(a->items >= (int)c1v_cdiv(a->M, VS_BM), "live_rows_table: the stream grid (%d workgroups) must cover all %d row tiles", a->items, (int)c1v_cdiv(a->M, VS_BM));
+    C1V_REQUIRE((a->rows != nullptr) == (a->cids != nullptr), "live_rows_table: rows / cids come together");
+    hipLaunchKernelGGL(live_rows_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, a->ids, a->M, a->items, a->vocab_tiles, a->max_splits,
+                       a->pos, a->ctl, a->rows, a->cids);
     C1V_LAUNCH_CHECK();
     return 0;
 }
@@ -1192,14 +1214,16 @@ extern "C" int c1v_cos_softmax_finish(const c1v_xent_finish_args* a, void* strea
     static const size_t lds = getenv("C1V_FINISH_LDS") ? (size_t)atoi(getenv("C1V_FINISH_LDS")) : 0;   // diagnostic: caps the resident waves per CU
     dim3 grid((unsigned)c1v_cdiv(M, 4));
     C1V_REQUIRE(a->ut_dtype == C1V_F32 || (a->ut_dtype == C1V_BF16 && a->dtype == C1V_BF16), "cos_softmax_finish: bf16 `ut` slabs come from the bf16 kernel only");
+    C1V_REQUIRE((a->live_rows != nullptr) == (a->live_ids != nullptr) && (a->live_rows == nullptr || (a->pos && a->live_ctl)),
+                "cos_softmax_finish: live_rows / live_ids come together, with pos and live_ctl");
 #define C1V_FINISH(ELEM, UB) hipLaunchKernelGGL((xent_finish_kernel<ELEM, UB>), grid, dim3(256), lds, (hipStream_t)stream, (const float*)a->ut, a->splits, a->kp, \
         a->m_pad, a->ones_col, (const ELEM*)a->yhat, (const ELEM*)a->w, a->rnorm, a->qscale, a->ids, a->B, a->T, a->V, a->B_global, a->xent_rows, a->dy, a->y, \
-        a->ldy, a->pos, a->live_ctl)
+        a->ldy, a->pos, a->live_ctl, a->live_rows, a->live_ids)
     if (a->dtype == C1V_F32) C1V_FINISH(float, false);
     else if (a->ut_dtype == C1V_BF16)
         hipLaunchKernelGGL(xent_finish_bf16_kernel, grid, dim3(256), lds, (hipStream_t)stream, (const float*)a->ut, a->splits, a->kp, a->m_pad,
                            a->ones_col, (const bf16_raw*)a->yhat, (const bf16_raw*)a->w, a->rnorm, a->qscale, a->ids, a->B, a->T, a->V, a->B_global,
-                           a->xent_rows, a->dy, a->y, a->ldy, a->pos, a->live_ctl);
+                           a->xent_rows, a->dy, a->y, a->ldy, a->pos, a->live_ctl, a->live_rows, a->live_ids);
     else C1V_FINISH(bf16_raw, false);
 #undef C1V_FINISH
     C1V_LAUNCH_CHECK();

@@ -33,12 +33,12 @@ __device__ __forceinline__ void loss_reduce_body(const float* __restrict__ xent_
                 for (int t = 0; t < T_len; t += 4) {
                     const float4 xv = *(const float4*)(xr + t);
                     const int4 iv = *(const int4*)(ir + t);
-                    s += xv.x; s += xv.y; s += xv.z; s += xv.w;
+                    s += iv.x >= 0 ? xv.x : 0.f; s += iv.y >= 0 ? xv.y : 0.f; s += iv.z >= 0 ? xv.z : 0.f; s += iv.w >= 0 ? xv.w : 0.f;
                     c += (iv.x >= 0 ? 1.f : 0.f); c += (iv.y >= 0 ? 1.f : 0.f); c += (iv.z >= 0 ? 1.f : 0.f); c += (iv.w >= 0 ? 1.f : 0.f);
                 }
             } else {
 #pragma unroll 8
-                for (int t = 0; t < T_len; ++t) { s += xr[t]; c += ir[t] >= 0 ? 1.f : 0.f; }
+                for (int t = 0; t < T_len; ++t) { s += ir[t] >= 0 ? xr[t] : 0.f; c += ir[t] >= 0 ? 1.f : 0.f; }
             }
             const float xb = s / c;
             if (xent_b) xent_b[b] = xb;
@@ -50,7 +50,10 @@ __device__ __forceinline__ void loss_reduce_body(const float* __restrict__ xent_
         // very long sequences: one wave per sample, lanes over the steps
         for (int b = wave; b < B; b += nwave) {
             float s = 0.f, c = 0.f;
-            for (int t = lane; t < T_len; t += 64) { s += xent_rows[(int64_t)b * T_len + t]; c += ids[(int64_t)b * T_len + t] >= 0 ? 1.f : 0.f; }
+            for (int t = lane; t < T_len; t += 64) {
+                const bool on = ids[(int64_t)b * T_len + t] >= 0;
+                s += on ? xent_rows[(int64_t)b * T_len + t] : 0.f; c += on ? 1.f : 0.f;
+            }
             s = wave_sum(s); c = wave_sum(c);
             const float xb = s / c;
             if (lane == 0 && xent_b) xent_b[b] = xb;
@@ -74,7 +77,10 @@ __device__ __forceinline__ void loss_sample_means_body(const float* __restrict__
     if (b >= B) return;
     const int lane = threadIdx.x & 63;
     float s = 0.f, c = 0.f;
-    for (int t = lane; t < T_len; t += 64) { s += xent_rows[(int64_t)b * T_len + t]; c += ids[(int64_t)b * T_len + t] >= 0 ? 1.f : 0.f; }
+    for (int t = lane; t < T_len; t += 64) {
+        const bool on = ids[(int64_t)b * T_len + t] >= 0;
+        s += on ? xent_rows[(int64_t)b * T_len + t] : 0.f; c += on ? 1.f : 0.f;
+    }
     s = wave_sum_dpp(s); c = wave_sum_dpp(c);
     if (lane == 0) xent_b[b] = s / c;
 }
@@ -97,8 +103,18 @@ constexpr int VS_CUS = 256;       // compute units of an MI355X: workgroups of t
 // waves' bases from LDS.  (Round 1 gave every THREAD a contiguous run: 64 lanes x 16 bytes 1 KB apart per request and one
 // request per round trip -- at C4, 262 k rows, 0.19 ms for this single block; 43 us now.  A one-pass form that keeps the
 // flags of 128 steps in registers was 36 us alone but its unrolled code cost the C2 prologue 7 us: not kept.)
+// rows / cids (optional): the inverse table -- rows[p] = m and cids[p] = ids[m] for the live row with position p -- so that
+// the finish step can run over the compacted rows only (c1v_xent_finish_args::live_rows)
+__device__ __forceinline__ void live_put4(int* __restrict__ rows, int* __restrict__ cids, const int4& v, const int4& o4, int m) {
+    if (rows == nullptr) return;
+    if (o4.x >= 0) { rows[o4.x] = m; cids[o4.x] = v.x; }
+    if (o4.y >= 0) { rows[o4.y] = m + 1; cids[o4.y] = v.y; }
+    if (o4.z >= 0) { rows[o4.z] = m + 2; cids[o4.z] = v.z; }
+    if (o4.w >= 0) { rows[o4.w] = m + 3; cids[o4.w] = v.w; }
+}
 __device__ __forceinline__ void live_rows_body(const int* __restrict__ ids, int M, int items, int vocab_tiles, int max_splits,
-                                               int* __restrict__ pos, int* __restrict__ ctl) {
+                                               int* __restrict__ pos, int* __restrict__ ctl, int* __restrict__ rows = nullptr,
+                                               int* __restrict__ cids = nullptr) {
     __shared__ int wsum[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x, nwave = nthr >> 6;
     constexpr int UN = 8;
@@ -144,6 +160,7 @@ __device__ __forceinline__ void live_rows_body(const int* __restrict__ ids, int 
             run += __shfl(sc, 63, 64);
             int4 o4;
             o4.x = v[u].x >= 0 ? p++ : -1; o4.y = v[u].y >= 0 ? p++ : -1; o4.z = v[u].z >= 0 ? p++ : -1; o4.w = v[u].w >= 0 ? p++ : -1;
+            live_put4(rows, cids, v[u], o4, m);
             if (vec && m + 3 < M) *(int4*)(pos + m) = o4;
             else {
                 if (m < M) pos[m] = o4.x;
@@ -176,7 +193,8 @@ __device__ __forceinline__ void live_rows_body(const int* __restrict__ ids, int 
 // live_rows_body, bit for bit (positions are integers).
 constexpr int LIVE_MB_MAX = 16;        // workgroups at most (beyond that the redundant counting outgrows what it saves)
 __device__ __forceinline__ void live_rows_mb_body(const int* __restrict__ ids, int M, int items, int vocab_tiles, int max_splits,
-                                                  int* __restrict__ pos, int* __restrict__ ctl, int blk, int nblk) {
+                                                  int* __restrict__ pos, int* __restrict__ ctl, int blk, int nblk,
+                                                  int* __restrict__ rows = nullptr, int* __restrict__ cids = nullptr) {
     __shared__ int wcnt[16], wbef[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x, nwave = nthr >> 6;
     const int R = nwave * 256;
@@ -214,6 +232,7 @@ __device__ __forceinline__ void live_rows_mb_body(const int* __restrict__ ids, i
     int p = base + sc - c;
     int4 o4;
     o4.x = own.x >= 0 ? p++ : -1; o4.y = own.y >= 0 ? p++ : -1; o4.z = own.z >= 0 ? p++ : -1; o4.w = own.w >= 0 ? p++ : -1;
+    live_put4(rows, cids, own, o4, m);
     if (vec && m + 3 < M) *(int4*)(pos + m) = o4;
     else {
         if (m < M) pos[m] = o4.x;

@@ -327,6 +327,9 @@ class VAEEngine:
         else:
             self.max_splits = max(self.x_splits, min(tiles, 16, (4 * 256) // tiles_m)) if self.compact else self.x_splits
         self.row_pos = torch.full((self.m_pad,), -1, dtype=torch.int32, device=self.dev)
+        # the inverse table (compact row -> sample row, target id): the finish step runs over the live rows only
+        self.live_rows_t = torch.zeros(self.m_pad, dtype=torch.int32, device=self.dev)
+        self.live_ids_t = torch.zeros(self.m_pad, dtype=torch.int32, device=self.dev)
         self.live_ctl = torch.zeros(8, dtype=torch.int32, device=self.dev)
         self.ut = torch.zeros(self.max_splits * self.kp * self.m_pad, dtype=torch.float32, device=self.dev)
         # the training pass of the fused kernel writes its partial sums as bf16 (half the bytes out of the kernel and
@@ -578,7 +581,7 @@ class VAEEngine:
                                             dstb.seq(length=dst_len), train)
             return ops
 
-        def out_conv(norm: bool, live_only: bool):
+        def out_conv(norm: bool, live_only: bool, zero_dy: bool = False):
             """The output convolution (a7).  norm: its epilogue also l2-normalises the rows into the loss kernel's operand
             (C1V_ROW_NORM: one workgroup holds a whole row) -- no c1v_l2norm_rows launch, no second pass over the fp32 rows."""
             e = self._epi(self.Y.seq(), L.ROW_NORM if norm else L.ROW_STORE, self._bias_ptr('deconv_decoder_embeddings/bias'))
@@ -586,6 +589,8 @@ class VAEEngine:
                 e.nrm_yhat, e.nrm_kp, e.nrm_rnorm, e.nrm_qscale = self.yhat.data_ptr(), self.kp, self.rnorm.data_ptr(), self.qscale
                 e.nrm_pos = self.row_pos.data_ptr() if self.compact else None
                 e.nrm_live_only = 1 if (live_only and self.compact) else 0
+                if zero_dy and self.finish_compact:
+                    e.nrm_dy = self.dOf.seq()
             return op('c1v_conv1d_fwd', L.ConvArgs(self.Xf.seq(), 0, g.output_text_size, k,
                                                    self.wop['out_fwd'].data_ptr(), self.wld['out_fwd'], self.V, e))
 
@@ -610,7 +615,10 @@ class VAEEngine:
                           (env_fn == '1' or k_tiles <= 12 or row_tiles >= 192))
         body_train = dec_fwd(True)
         body_infer = dec_fwd(False) if bn else body_train
-        self.ops_dec_train = body_train + [out_conv(self.fuse_norm, os.environ.get('C1V_NORM_LIVE_ONLY', '1') != '0')]
+        # the finish step over the compacted rows only: the output convolution's epilogue writes the zero gradient rows of the
+        # positions without a target, the live-row table comes with its inverse (C1V_FINISH_COMPACT=0: one wave per row)
+        self.finish_compact = bool(self.fuse_norm and self.compact and os.environ.get('C1V_FINISH_COMPACT', '1') != '0')
+        self.ops_dec_train = body_train + [out_conv(self.fuse_norm, os.environ.get('C1V_NORM_LIVE_ONLY', '1') != '0', True)]
         self.ops_dec_infer = body_infer + [out_conv(False, False)]
         self.ops_dec_eval = body_infer + [out_conv(True, False)] if self.fuse_norm else self.ops_dec_infer
         self.ops_dec = self.ops_dec_train
@@ -631,12 +639,11 @@ class VAEEngine:
         pos_ptr = self.row_pos.data_ptr() if self.compact else None
         ctl_ptr = self.live_ctl.data_ptr() if self.compact else None
 
-        def live_rows():
-            L.check(f_live(self.ids_in.data_ptr(), self.M, (self.m_pad // 128) * self.x_splits, self.n_pad // 64,
-                           self.max_splits, self.row_pos.data_ptr(), self.live_ctl.data_ptr(), self._stream()), 'c1v_live_rows')
-        self.ops_live_rows = [live_rows] if self.compact else []
         self._live_args = L.LiveRowsArgs(self.ids_in.data_ptr(), self.M, (self.m_pad // 128) * self.x_splits, self.n_pad // 64,
-                                         self.max_splits, self.row_pos.data_ptr(), self.live_ctl.data_ptr())
+                                         self.max_splits, self.row_pos.data_ptr(), self.live_ctl.data_ptr(),
+                                         self.live_rows_t.data_ptr() if self.finish_compact else None,
+                                         self.live_ids_t.data_ptr() if self.finish_compact else None)
+        self.ops_live_rows = [op('c1v_live_rows_table', self._live_args)] if self.compact else []
 
         def loss_ops(train: bool):
             ops = [] if self.fuse_norm else [
@@ -652,7 +659,9 @@ class VAEEngine:
                 self.w_vocab.data_ptr(), self.code, self.rnorm.data_ptr(), self.qscale, self.ids_in.data_ptr(), B,
                 g.output_text_size, self.V, self.Bg, self.xent_rows.data_ptr(), self.xent_b.data_ptr(),
                 self.dOf.seq() if train else _null_seq(), self.Y.t.data_ptr(), self.Vp, pos_ptr, ctl_ptr,
-                self.ut_code if train else L.F32)))
+                self.ut_code if train else L.F32,
+                self.live_rows_t.data_ptr() if self.finish_compact else None,
+                self.live_ids_t.data_ptr() if self.finish_compact else None)))
             core = list(ops)
             if not self.fuse_norm:                         # (fused: the output convolution already needs the positions)
                 ops = self.ops_live_rows + ops

@@ -93,6 +93,9 @@ typedef struct c1v_epilogue {
                                    are not multiples of 4; bias index = t*bias_row_w + c, pad channels get 0.  0 = no padding */
     /* C1V_ROW_NORM only (see above; the arguments of c1v_l2norm_args) */
     void*          nrm_yhat; int32_t nrm_kp; float* nrm_rnorm; float nrm_qscale; const int32_t* nrm_pos; int32_t nrm_live_only;
+    c1v_seq        nrm_dy;      /* optional (data != NULL, with nrm_pos): rows without a target get an all-zero row (b, u) of this
+                                   buffer -- the gradient of the loss w.r.t. y, which c1v_cos_softmax_finish then writes for the
+                                   live rows only (c1v_xent_finish_args::live_rows) */
 } c1v_epilogue;
 
 /* ---- a1 / a6 / a7: Conv1D('valid'|'same') and Conv2DTranspose((k,1)) forward (:1227-1280) -------------
@@ -320,6 +323,11 @@ typedef struct c1v_xent_finish_args {
     const int32_t* pos;            /* optional: compact row of yhat / ut for sample row m (c1v_live_rows); < 0: no target */
     const int32_t* live_ctl;       /* optional: number of ut slabs = live_ctl[2] instead of `splits` */
     int32_t ut_dtype;              /* element type of the `ut` slabs, as given to c1v_cos_softmax_accum */
+    const int32_t* live_rows; const int32_t* live_ids;   /* optional (c1v_live_rows_args::rows / cids, with pos and live_ctl): one
+                                      wave per LIVE row -- compact row p < live_ctl[0] is sample row live_rows[p] with target
+                                      live_ids[p]; rows without a target are not visited at all: their xent_rows are left alone
+                                      (c1v_loss_reduce masks by ids) and their dy rows must be zero already (C1V_ROW_NORM's
+                                      nrm_dy writes them) */
 } c1v_xent_finish_args;
 int c1v_cos_softmax_finish(const c1v_xent_finish_args*, void* stream);
 /* Rows without a target (ids[m] < 0: padding behind the end of a text) contribute exactly zero to the loss and to its
@@ -335,7 +343,12 @@ int c1v_cos_softmax_finish(const c1v_xent_finish_args*, void* stream);
  * `items` = workgroups of the c1v_cos_softmax_accum grid = (m_pad/128) * splits >= ctl[4] + remaining * ctl[2];
  * vocab_tiles = n_pad/64. */
 int c1v_live_rows(const int32_t* ids, int32_t M, int32_t items, int32_t vocab_tiles, int32_t max_splits, int32_t* pos, int32_t* ctl, void* stream);
-typedef struct c1v_live_rows_args { const int32_t* ids; int32_t M, items, vocab_tiles, max_splits; int32_t* pos; int32_t* ctl; } c1v_live_rows_args;
+typedef struct c1v_live_rows_args {
+    const int32_t* ids; int32_t M, items, vocab_tiles, max_splits; int32_t* pos; int32_t* ctl;
+    int32_t* rows; int32_t* cids;   /* optional, both or neither: the inverse table rows[p] = m, cids[p] = ids[m] of the live row
+                                       at position p (for c1v_xent_finish_args::live_rows) */
+} c1v_live_rows_args;
+int c1v_live_rows_table(const c1v_live_rows_args*, void* stream);     /* c1v_live_rows behind its argument struct (+ rows / cids) */
 /* c1v_live_rows + c1v_gather_input as ONE launch (no counterpart in the reference: two independent jobs of a large batch's
  * step; block 0 builds the live-row table with 16 waves, the other blocks assemble the encoder operand) */
 int c1v_live_rows_gather(const c1v_live_rows_args* live, const c1v_gather_input_args* gather, void* stream);

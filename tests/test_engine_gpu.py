@@ -410,6 +410,44 @@ def test_all_weight_gradients_in_one_launch_are_bit_identical(name, dtype, monke
         np.testing.assert_array_equal(got[mode][2], got['0'][2], err_msg=mode)
 
 
+@pytest.mark.parametrize('name', ['mid', 'wide', 'big128', 'kp320', 'ragged'])
+def test_finish_step_over_the_live_rows_only_is_bit_identical(name, monkeypatch):
+    """c1v_xent_finish_args::live_rows (one wave per LIVE row through the inverse live-row table; the zero gradient rows of
+    the positions without a target written by the output convolution's epilogue, C1V_ROW_NORM's nrm_dy) against one wave per
+    row: the same arithmetic per live row and zeros elsewhere, so the gradient buffer, every gradient, the loss scalars and
+    a three-step Nadam trajectory agree to the bit.  The step is run twice with different targets in between, so that rows
+    that were live and are not any more must have been zeroed again."""
+    c = CASES[name]
+    og, params, Wv, x, ids, eps, mask_e, mask_d = make_case(c)
+    ids2 = ids.copy()
+    ids2[:, ids.shape[1] // 3:] = -1                     # shorter texts: most live rows of `ids` are dead here
+    got = {}
+    for mode in ('1', '0'):
+        monkeypatch.setenv('C1V_FINISH_COMPACT', mode)
+        eng = build_engine(c, og, params, Wv, 'bf16')
+        if mode == '1' and not eng.finish_compact:
+            pytest.skip('this shape does not take the whole-row output convolution')
+        assert eng.finish_compact == (mode == '1')
+        res = []
+        for ids_k in (ids, ids2, ids):
+            load_fixed(eng, x, ids_k, eps, mask_e, mask_d)
+            eng._run(eng.train_ops(False))
+            torch.cuda.synchronize()
+            res.append((eng.get_grads(), eng.loss_out.cpu().numpy().copy(), eng.dOf.valid().float().cpu().numpy().copy()))
+        for _ in range(3):
+            eng.train_step(use_graph=True, fixed_rng=True)
+        eng.eval_step(use_graph=False, fixed_rng=True)
+        torch.cuda.synchronize()
+        got[mode] = (res, eng.params.cpu().numpy().copy(), eng.loss())
+    for (ga, la, da), (gb, lb, db) in zip(got['1'][0], got['0'][0]):
+        np.testing.assert_array_equal(la, lb)
+        np.testing.assert_array_equal(da, db)
+        for k_, v in gb.items():
+            np.testing.assert_array_equal(ga[k_], v, err_msg=k_)
+    np.testing.assert_array_equal(got['1'][1], got['0'][1])
+    assert got['1'][2] == got['0'][2]
+
+
 @pytest.mark.parametrize('name', ['mid', 'deep3'])
 def test_loss_scalars_with_the_per_sample_means_in_their_own_launch(name, monkeypatch):
     """Large batches (>= 65 536 target rows) sum the per-step losses of a sample in c1v_loss_sample_means (one wave per

@@ -313,21 +313,33 @@ def test_live_row_table_from_several_workgroups_matches_the_single_workgroup(M):
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     items, vocab_tiles, max_splits = max(256, -(-M // 128)), 128, 16
     res = []
-    for which in ('prologue', 'single'):
+    live = ids >= 0
+    n_live = int(live.sum())
+    for which in ('prologue', 'table', 'single'):
         pos = torch.full((M + 8,), -7, dtype=torch.int32, device=dev)
         ctl = torch.zeros(8, dtype=torch.int32, device=dev)
-        la = L.LiveRowsArgs(t_ids.data_ptr(), M, items, vocab_tiles, max_splits, pos.data_ptr(), ctl.data_ptr())
+        rows = torch.full((M + 8,), -7, dtype=torch.int32, device=dev)
+        cids = torch.full((M + 8,), -7, dtype=torch.int32, device=dev)
+        la = L.LiveRowsArgs(t_ids.data_ptr(), M, items, vocab_tiles, max_splits, pos.data_ptr(), ctl.data_ptr(),
+                            rows.data_ptr(), cids.data_ptr())
         if which == 'prologue':
             a = L.StepPrologueArgs()
             a.live = C.pointer(la)
             L.check(lib.c1v_step_prologue(C.byref(a), st), 'c1v_step_prologue')
+        elif which == 'table':
+            L.check(lib.c1v_live_rows_table(C.byref(la), st), 'c1v_live_rows_table')
         else:
             L.check(lib.c1v_live_rows(t_ids.data_ptr(), M, items, vocab_tiles, max_splits, pos.data_ptr(), ctl.data_ptr(), st), 'c1v_live_rows')
         torch.cuda.synchronize()
+        if which != 'single':
+            # the inverse table: compact row p -> (sample row, target id); nothing written behind the last live row
+            np.testing.assert_array_equal(rows.cpu().numpy()[:n_live], np.nonzero(live)[0].astype(np.int32))
+            np.testing.assert_array_equal(cids.cpu().numpy()[:n_live], ids[live])
+            assert np.all(rows.cpu().numpy()[n_live:] == -7) and np.all(cids.cpu().numpy()[n_live:] == -7)
         res.append((pos.cpu().numpy(), ctl.cpu().numpy()))
-    np.testing.assert_array_equal(res[0][0], res[1][0])
-    np.testing.assert_array_equal(res[0][1], res[1][1])
-    live = ids >= 0
+    for k in (0, 1):
+        np.testing.assert_array_equal(res[k][0], res[2][0])
+        np.testing.assert_array_equal(res[k][1], res[2][1])
     want = np.where(live, np.cumsum(live) - 1, -1).astype(np.int32)
     np.testing.assert_array_equal(res[0][0][:M], want)
-    assert np.all(res[0][0][M:] == -7) and res[0][1][0] == int(live.sum())
+    assert np.all(res[0][0][M:] == -7) and res[0][1][0] == n_live
