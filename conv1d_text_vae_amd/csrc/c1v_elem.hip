@@ -829,12 +829,19 @@ extern "C" int c1v_philox_multi(const c1v_rng_desc* descs, int32_t n_desc, int32
 // Large batches (see VAEEngine._input_own_launch): the live-row table and the encoder operand in ONE launch of 1024-thread
 // blocks -- block 0 scans the targets with 16 waves, the others assemble the input; neither needs the other's result.
 struct LiveGatherDev {
-    const int* ids; int M, items, vocab_tiles, max_splits; int* pos; int* ctl; int* rows; int* cids;
+    const int* ids; int M, items, vocab_tiles, max_splits; int* pos; int* ctl; int* rows; int* cids; int live_blocks;
     const float* table; int64_t ld; const int* in_ids; int T, C; c1v_seq dst; int in_blocks, in_dtype;
 };
 __global__ __launch_bounds__(1024) void live_gather_kernel(const LiveGatherDev d) {
-    if (blockIdx.x == 0) { live_rows_body(d.ids, d.M, d.items, d.vocab_tiles, d.max_splits, d.pos, d.ctl, d.rows, d.cids); return; }
-    const int blk = (int)blockIdx.x - 1;
+    // the live-row table: several workgroups of 4 096 rows, each counting the rows in front of its range itself
+    // (live_rows_mb_body; one workgroup walking C4's 270 k rows took 43 us, 120 with the inverse table's scattered stores
+    // -- longer than the gather it shares the launch with)
+    if ((int)blockIdx.x < d.live_blocks) {
+        if (d.live_blocks > 1) live_rows_mb_body(d.ids, d.M, d.items, d.vocab_tiles, d.max_splits, d.pos, d.ctl, (int)blockIdx.x, d.live_blocks, d.rows, d.cids);
+        else live_rows_body(d.ids, d.M, d.items, d.vocab_tiles, d.max_splits, d.pos, d.ctl, d.rows, d.cids);
+        return;
+    }
+    const int blk = (int)blockIdx.x - d.live_blocks;
     if (d.in_dtype == C1V_F32) gather_input_body<float>(d.table, d.ld, d.in_ids, d.T, d.C, d.dst, blk, d.in_blocks);
     else gather_input_body<bf16_raw>(d.table, d.ld, d.in_ids, d.T, d.C, d.dst, blk, d.in_blocks);
 }
@@ -854,7 +861,10 @@ extern "C" int c1v_live_rows_gather(const c1v_live_rows_args* l, const c1v_gathe
     const int64_t total = (int64_t)a->dst.batch * a->T * (a->dst.cp / 8);
     int64_t nb = c1v_cdiv(total, 1024 * 4);                        // ~4 eight-element groups per thread
     d.in_blocks = (int)(nb < 1 ? 1 : (nb > 4096 ? 4096 : nb));
-    hipLaunchKernelGGL(live_gather_kernel, dim3((unsigned)(1 + d.in_blocks)), dim3(1024), 0, (hipStream_t)stream, d);
+    const int lb = (int)c1v_cdiv(l->M, 4096);
+    const char* env_mb = getenv("C1V_LIVE_MB");
+    d.live_blocks = (lb <= 256 && !(env_mb && env_mb[0] == '0')) ? lb : 1;
+    hipLaunchKernelGGL(live_gather_kernel, dim3((unsigned)(d.live_blocks + d.in_blocks)), dim3(1024), 0, (hipStream_t)stream, d);
     C1V_LAUNCH_CHECK();
     return 0;
 }

@@ -210,12 +210,13 @@ __device__ __forceinline__ void live_rows_mb_body(const int* __restrict__ ids, i
     const int m = r0 + wave * 256 + 4 * lane;
     const int4 own = load4(m);
     int before = 0;
-    for (int q0 = 4 * tid; q0 < r0; q0 += 4 * nthr * 4) {
-        int4 v[4];
+    constexpr int PU = 8;                              // requests per thread and round of the prefix count
+    for (int q0 = 4 * tid; q0 < r0; q0 += 4 * nthr * PU) {
+        int4 v[PU];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { const int q = q0 + u * 4 * nthr; v[u] = q < r0 ? load4(q) : make_int4(-1, -1, -1, -1); }
+        for (int u = 0; u < PU; ++u) { const int q = q0 + u * 4 * nthr; v[u] = q < r0 ? load4(q) : make_int4(-1, -1, -1, -1); }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) before += (v[u].x >= 0) + (v[u].y >= 0) + (v[u].z >= 0) + (v[u].w >= 0);
+        for (int u = 0; u < PU; ++u) before += (v[u].x >= 0) + (v[u].y >= 0) + (v[u].z >= 0) + (v[u].w >= 0);
     }
     const int c = (own.x >= 0) + (own.y >= 0) + (own.z >= 0) + (own.w >= 0);
     int sc = c;                                        // inclusive scan of the step over the lanes

@@ -343,3 +343,48 @@ def test_live_row_table_from_several_workgroups_matches_the_single_workgroup(M):
     want = np.where(live, np.cumsum(live) - 1, -1).astype(np.int32)
     np.testing.assert_array_equal(res[0][0][:M], want)
     assert np.all(res[0][0][M:] == -7) and res[0][1][0] == n_live
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('M', [3000, 4096, 70000, 270336])
+def test_live_row_table_of_the_large_batch_launch(M):
+    """c1v_live_rows_gather (large batches: live-row table + input gather in one launch of 1 024-thread workgroups) builds
+    the table -- positions, control block and the inverse table -- with one workgroup per 4 096 rows; against c1v_live_rows
+    and NumPy.  The gather half of the launch is given a tiny job of its own and checked too."""
+    from conv1d_text_vae_amd import _lib as L
+    lib = L.load()
+    dev = torch.device('cuda:0')
+    rng = np.random.RandomState(M % 9973)
+    ids = rng.randint(-3, 1000, size=M).astype(np.int32)
+    ids[ids < 0] = -1
+    ids[M // 3: M // 3 + 5000] = -1
+    t_ids = torch.from_numpy(ids).to(dev)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    items, vocab_tiles, max_splits = max(256, -(-M // 128)) * 2, 512, 8
+    live = ids >= 0
+    n_live = int(live.sum())
+    # gather job: 4 samples x 6 steps of a 40-column table into a bf16 operand with 64-channel rows
+    Bg, Tg, Cg, cp = 4, 6, 40, 64
+    table = torch.from_numpy(rng.randn(50, Cg).astype(np.float32)).to(dev)
+    gid = torch.from_numpy(rng.randint(-1, 50, size=(Bg, Tg)).astype(np.int32)).to(dev)
+    dst = torch.zeros(Bg * 8 * cp + 4096, dtype=torch.bfloat16, device=dev)
+    ga = L.GatherInputArgs(table.data_ptr(), Cg, gid.data_ptr(), Tg, Cg, L.Seq(dst.data_ptr(), L.BF16, Bg, 8 * cp, 1, Tg, cp, Cg))
+    pos = torch.full((M + 8,), -7, dtype=torch.int32, device=dev)
+    ctl = torch.zeros(8, dtype=torch.int32, device=dev)
+    rows = torch.full((M + 8,), -7, dtype=torch.int32, device=dev)
+    cids = torch.full((M + 8,), -7, dtype=torch.int32, device=dev)
+    la = L.LiveRowsArgs(t_ids.data_ptr(), M, items, vocab_tiles, max_splits, pos.data_ptr(), ctl.data_ptr(), rows.data_ptr(), cids.data_ptr())
+    L.check(lib.c1v_live_rows_gather(C.byref(la), C.byref(ga), st), 'c1v_live_rows_gather')
+    pos1 = torch.full((M + 8,), -7, dtype=torch.int32, device=dev)
+    ctl1 = torch.zeros(8, dtype=torch.int32, device=dev)
+    L.check(lib.c1v_live_rows(t_ids.data_ptr(), M, items, vocab_tiles, max_splits, pos1.data_ptr(), ctl1.data_ptr(), st), 'c1v_live_rows')
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(pos.cpu().numpy(), pos1.cpu().numpy())
+    np.testing.assert_array_equal(ctl.cpu().numpy(), ctl1.cpu().numpy())
+    np.testing.assert_array_equal(pos.cpu().numpy()[:M], np.where(live, np.cumsum(live) - 1, -1).astype(np.int32))
+    np.testing.assert_array_equal(rows.cpu().numpy()[:n_live], np.nonzero(live)[0].astype(np.int32))
+    np.testing.assert_array_equal(cids.cpu().numpy()[:n_live], ids[live])
+    assert np.all(rows.cpu().numpy()[n_live:] == -7) and int(ctl.cpu().numpy()[0]) == n_live
+    got = dst[:Bg * 8 * cp].float().cpu().numpy().reshape(Bg, 8, cp)[:, 1:1 + Tg, :Cg]
+    want = np.where(gid.cpu().numpy()[:, :, None] >= 0, table.cpu().numpy()[np.maximum(gid.cpu().numpy(), 0)], 0.0)
+    np.testing.assert_allclose(got, want, rtol=2 ** -8, atol=0)
