@@ -237,8 +237,16 @@ extern "C" int c1v_run_list_fork(int32_t n, const c1v_op_fn* fns, const void* co
         open_side = false;
         return 0;
     };
+    // An entry that fails ends the list; what was already issued on `side` is still joined, so that the caller's
+    // synchronisation of `stream` covers it (the entry's own error text is kept).
+    auto fail = [&]() {
+        if (!open_side) return;
+        const std::string keep = g_err;
+        join();
+        g_err = keep;
+    };
+    for (int32_t i = 0; i < n; ++i) C1V_REQUIRE(fns[i] != nullptr, "run_list_fork: entry %d has no function", i);
     for (int32_t i = 0; i < n; ++i) {
-        C1V_REQUIRE(fns[i] != nullptr, "run_list_fork: entry %d has no function", i);
         const int f = flags[i];
         if (f & C1V_LIST_SIDE) {
             if (f & C1V_LIST_FORK) {
@@ -248,11 +256,11 @@ extern "C" int c1v_run_list_fork(int32_t n, const c1v_op_fn* fns, const void* co
             }
             open_side = true;
             const int rc = fns[i](args[i], side);
-            if (rc != 0) return rc;
+            if (rc != 0) { fail(); return rc; }
         } else {
             if ((f & C1V_LIST_JOIN) && open_side && join()) return -1;
             const int rc = fns[i](args[i], stream);
-            if (rc != 0) return rc;
+            if (rc != 0) { fail(); return rc; }
         }
     }
     if (open_side && join()) return -1;
