@@ -143,6 +143,10 @@ class WgradBatchArgs(C.Structure):
     _fields_ = [('n', C.c_int32), ('items', C.POINTER(WgradArgs) * WGRAD_BATCH_MAX)]
 
 
+class DecHeadArgs(C.Structure):
+    _fields_ = [('latent', C.POINTER(LatentArgs)), ('dense', C.POINTER(DenseArgs)), ('deconv', C.POINTER(ConvArgs))]
+
+
 class GradFinalizeArgs(C.Structure):
     _fields_ = [('segs', C.c_void_p), ('n_seg', C.c_int32), ('total_blocks', C.c_int32), ('grad', C.c_void_p),
                 ('sq_partial', C.c_void_p), ('loss', C.c_void_p)]
@@ -233,6 +237,8 @@ SYMBOLS = {
                          C.c_void_p, C.c_void_p], C.c_int),
     'c1v_grad_finalize': ([C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p], C.c_int),
     'c1v_wgrad_batch': ([_P(WgradBatchArgs), C.c_void_p], C.c_int),
+    'c1v_dec_head_fwd': ([_P(DecHeadArgs), C.c_void_p], C.c_int),
+    'c1v_dec_head_fwd_check': ([_P(DecHeadArgs)], C.c_int),
     'c1v_loss_sample_means': ([_P(LossReduceArgs), C.c_void_p], C.c_int),
     'c1v_grad_finalize_step': ([_P(GradFinalizeArgs), C.c_void_p], C.c_int),
     'c1v_grad_finalize_loss': ([C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, _P(LossReduceArgs), C.c_void_p],

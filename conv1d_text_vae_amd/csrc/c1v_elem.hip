@@ -214,7 +214,10 @@ __global__ __launch_bounds__(256) void latent_fwd_kernel(c1v_latent_args a) {
     const float* m = a.mlv + (int64_t)b * 2 * a.D;
     const float* lv = m + a.D;
     const float* ep = a.eps + (int64_t)b * a.D;
-    const uint8_t* kd = a.keep_d ? a.keep_d + (int64_t)b * a.D : nullptr;
+    const bool kd = a.keep_d != nullptr;
+    // (the mask bytes are loaded unconditionally -- from eps when there is no mask, and ignored: a load under a condition
+    // compiles to a branch that waits for it at once, one exposed memory round trip per round)
+    const uint8_t* kdp = kd ? a.keep_d + (int64_t)b * a.D : (const uint8_t*)ep;
     float kl = 0.f;
     for (int d0 = 0; d0 < a.D; d0 += 256) {
         float mv[4], l[4], e[4];
@@ -223,7 +226,7 @@ __global__ __launch_bounds__(256) void latent_fwd_kernel(c1v_latent_args a) {
         for (int r = 0; r < 4; ++r) {
             const int d = d0 + lane + 64 * r, dc = d < a.D ? d : a.D - 1;
             mv[r] = m[dc]; l[r] = lv[dc]; e[r] = ep[dc];
-            k[r] = kd ? kd[dc] : (uint8_t)1;
+            k[r] = kdp[dc];
         }
         if (a.n_parts > 1) {
             // split-K heads GEMM: mlv arrives as partial slabs; sum them in slab order and write the sum back to slab 0
@@ -267,7 +270,6 @@ __global__ __launch_bounds__(256) void latent_fwd_kernel(c1v_latent_args a) {
     kl = wave_sum(kl);
     if (lane == 0 && a.kl_out) a.kl_out[b] = kl / (float)a.D;
 }
-
 __global__ __launch_bounds__(256) void latent_bwd_kernel(c1v_latent_args a) {
     const int64_t total = (int64_t)a.B * a.D;
     const float kc = 1.0f / ((float)a.D * (float)a.B_global);
@@ -295,6 +297,328 @@ extern "C" int c1v_latent_head_bwd(const c1v_latent_args* a, void* stream) {
     C1V_REQUIRE(a && a->mlv && a->eps && a->dzd && a->dmlv, "latent_head_bwd: null argument");
     C1V_REQUIRE(a->B > 0 && a->D > 0 && a->ldd >= 2 * a->D && a->B_global > 0 && a->keep_prob > 0.f, "latent_head_bwd: bad shape");
     hipLaunchKernelGGL(latent_bwd_kernel, dim3(grid_for((int64_t)a->B * a->D)), dim3(256), 0, (hipStream_t)stream, *a);
+    C1V_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// c1v_dec_head_fwd: latent head -> decoder dense -> first transposed convolution in ONE launch (small batches).
+// As launches of their own the three are 6.4 + 6.1 + 5.2 us at C2 and almost all of that is latency: launch, argument
+// fetch, one memory round trip in, one store drain out, three times over, for 0.1 GFLOP.  Here a workgroup owns DH_G samples
+// from the partial sums of the heads GEMM to the up-sampled output of the transposed convolution; what the stages hand to
+// each other stays in LDS (the buffers the backward pass reads are written on the side), and both weight operands are
+// requested as MFMA fragments before the first stage starts.  Same MFMA instruction, same order of the K steps and the
+// same epilogue arithmetic as the GEMM kernels: results are bit-identical to the three launches.
+// ------------------------------------------------------------------------------------------------------
+constexpr int DH_G = 4;          // samples per workgroup
+constexpr int DH_W = 16;         // waves: four per SIMD -- every stage is short chains of dependent memory / LDS operations, and
+                                 // with one wave per SIMD (first version: 41 k cycles per workgroup, 15 k of them spent ISSUING
+                                 // 144 loads per wave through the 63-deep counter) nothing hides them
+constexpr int DH_NBW = 2;        // dense: 16-column blocks per wave            (n_out <= 16 * 2 * 16 = 512)
+constexpr int DH_KSD = 8;        // dense: 32-element K steps                   (K <= 256)
+constexpr int DH_RBW = 4;        // transposed convolution: 16-row blocks per wave, two wave groups  (DH_G * n_rows <= 128)
+constexpr int DH_KSC = 4;        //   32-element K steps                        (k * cp <= 128)
+                                 //   one 16-column block per wave, eight blocks (n_out <= 128)
+struct DecHeadDev {
+    c1v_latent_args lat;
+    const bf16_raw* wd; int64_t ldwd; int Kd, Nd, reshape_w, bias_row_w, relu_d; const float* bias_d;
+    bf16_raw* xd; int64_t xd_bstride; int xd_off, xd_len, xd_cp, pitch;
+    const bf16_raw* wc; int64_t ldwc; int k, n_rows, F, relu_c; const float* bias_c;
+    bf16_raw* xf; int64_t xf_bstride; int xf_off, xf_len, xf_cp;
+    int lds_img, lds_park, lds_kl, lds_total;  // byte offsets: input image of the convolution, its parked output, KL partial sums
+};
+// (LDS hand-offs inside the workgroup: wait for this wave's LDS writes only, then the barrier.  __syncthreads() would also
+// wait for every global load and store in flight -- the weight fragments requested ahead, the side stores of the buffers)
+__device__ __forceinline__ void dh_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+#ifdef DH_STAMP
+// diagnostic build only: s_memtime stamps of wave 0 of every workgroup
+__device__ unsigned long long dh_dbg[16 * 1024];
+#define DH_T(i) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp[i]) :: "memory"); \
+    __builtin_amdgcn_sched_barrier(0); } while (0)
+extern "C" int c1v_debug_read_dh(unsigned long long* dst, int n) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(dh_dbg), sizeof(unsigned long long) * n);
+}
+#else
+#define DH_T(i) do {} while (0)
+#endif
+__global__ __launch_bounds__(64 * DH_W) void dec_head_fwd_kernel(const DecHeadDev p) {
+#ifdef DH_STAMP
+    unsigned long long stamp[16];
+#endif
+    DH_T(0);
+    c1v_touch_kernarg<6>();
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, r = lane & 15;
+    const int b0 = blockIdx.x * DH_G;
+    bf16_raw* zd_img = (bf16_raw*)smem;                        // [16][Kd]   dense operand (rows >= DH_G stay zero)
+    bf16_raw* x_img = (bf16_raw*)(smem + p.lds_img);           // [DH_G][pitch][cp]  = the samples' rows of the buffer `xd`
+    bf16_raw* park = (bf16_raw*)(smem + p.lds_park);           // [DH_G * n_rows][F]
+    float* klp = (float*)(smem + p.lds_kl);                    // [DH_G][4][64]
+    // ---- latent head: wave w = columns lane + 64 (w / 4) of sample b0 + w % 4 (c1v_latent_head_fwd's arithmetic for D <= 256 and
+    // <= 8 partial slabs, same order of the additions).  Its loads are requested first: they are the critical path, the weight
+    // fragments behind them arrive while the latent values are formed.  No load sits under a condition (a conditional load
+    // compiles to a branch that waits for it at once): indices are clamped, values masked.
+    const c1v_latent_args& a = p.lat;
+    const int es = wave & 3, q = wave >> 2;
+    const int b = b0 + es;
+    const bool have_b = b < a.B;
+    const int bcl = have_b ? b : a.B - 1;
+    const int d = lane + 64 * q, dc = d < a.D ? d : a.D - 1;
+    const bool have_d = have_b && d < a.D;
+    const float* m = a.mlv + (int64_t)bcl * 2 * a.D;
+    const float* lv = m + a.D;
+    const float* ep = a.eps + (int64_t)bcl * a.D;
+    const bool kd = a.keep_d != nullptr;
+    const uint8_t* kdp = kd ? a.keep_d + (int64_t)bcl * a.D : (const uint8_t*)ep;     // (no mask: bytes of eps, ignored)
+    float mv = m[dc], l = lv[dc];
+    const float e1 = ep[dc];
+    const uint8_t k1 = kdp[dc];
+    float pm[7], pl[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+        const int64_t so = (int64_t)(1 + i < a.n_parts ? 1 + i : (a.n_parts > 0 ? a.n_parts - 1 : 0)) * a.part_stride;
+        pm[i] = m[so + dc]; pl[i] = lv[so + dc];
+    }
+    // the epilogues' bias values
+    float bias_dv[DH_NBW], bias_cv;
+    int t_d[DH_NBW], c_d[DH_NBW];
+    {
+        const float* bdp = p.bias_d ? p.bias_d : a.eps;
+#pragma unroll
+        for (int i = 0; i < DH_NBW; ++i) {
+            const int n = (wave + DH_W * i) * 16 + r, nc = n < p.Nd ? n : p.Nd - 1;
+            const int t = nc / p.reshape_w, c = nc - t * p.reshape_w;
+            t_d[i] = t; c_d[i] = c;
+            const int bi = p.bias_row_w > 0 ? t * p.bias_row_w + (c < p.bias_row_w ? c : p.bias_row_w - 1) : nc;
+            bias_dv[i] = bdp[bi];
+            if (!p.bias_d || (p.bias_row_w > 0 && c >= p.bias_row_w)) bias_dv[i] = 0.f;
+        }
+        const float* bcp = p.bias_c ? p.bias_c : a.eps;
+        const int f = (wave & 7) * 16 + r;
+        bias_cv = bcp[f < p.F ? f : p.F - 1];
+        if (!p.bias_c) bias_cv = 0.f;
+    }
+    // both weight operands as MFMA fragments (lane (r, g): operand row = column block * 16 + r, 8 K values from 8 g), in the
+    // order the K steps consume them.  Dense: wave w owns column blocks w and w + 16; transposed convolution: column block
+    // w % 8 and the row blocks w / 8, w / 8 + 2, ...
+    const int ksd = p.Kd >> 5, ksc = (p.k * p.xd_cp) >> 5;
+    uint4 bd[DH_NBW][DH_KSD], bc[DH_KSC];
+#pragma unroll
+    for (int s2 = 0; s2 < DH_KSD; ++s2)
+#pragma unroll
+        for (int i = 0; i < DH_NBW; ++i) {
+            const int n = (wave + DH_W * i) * 16 + r;
+            const bf16_raw* src = p.wd + (int64_t)(n < p.Nd ? n : p.Nd - 1) * p.ldwd + 8 * g;
+            bd[i][s2] = *(const uint4*)(src + 32 * (s2 < ksd ? s2 : ksd - 1));      // (clamped; surplus blocks / steps are never used)
+        }
+    {
+        const int f = (wave & 7) * 16 + r;
+        const bf16_raw* src = p.wc + (int64_t)(f < p.F ? f : p.F - 1) * p.ldwc + 8 * g;
+#pragma unroll
+        for (int s2 = 0; s2 < DH_KSC; ++s2) bc[s2] = *(const uint4*)(src + 32 * (s2 < ksc ? s2 : ksc - 1));
+    }
+    DH_T(1);
+    for (int i = tid * 16; i < p.lds_park; i += 64 * DH_W * 16) *(uint4*)(smem + i) = make_uint4(0u, 0u, 0u, 0u);
+    dh_barrier();
+    DH_T(2);
+    if (a.n_parts > 1) {
+#pragma unroll
+        for (int i = 0; i < 7; ++i)
+            if (1 + i < a.n_parts) { mv += pm[i]; l += pl[i]; }
+        if (have_d) { ((float*)m)[d] = mv; ((float*)lv)[d] = l; }
+    }
+    {
+        float klq = 0.f;
+        if (have_d) {
+            const float z = mv + expf(a.std_scale * l) * e1;
+            klq = 1.0f + l - mv * mv - expf(l);
+            if (a.z_out) a.z_out[(int64_t)b * a.D + d] = z;
+            float zd = z;
+            if (kd) zd = k1 ? z / a.keep_prob : 0.0f;
+            const bf16_raw h = f32_to_bf16(zd);
+            ((bf16_raw*)a.zd_out)[(int64_t)b * a.ldz + d] = h;
+            zd_img[es * p.Kd + d] = h;
+        }
+        klp[(es * 4 + q) * 64 + lane] = klq;
+    }
+    DH_T(3);
+    dh_barrier();
+    DH_T(4);
+    if (q == 0 && have_b && a.kl_out) {
+        // per lane in column-quarter order, then across the lanes: the order of the one-wave-per-sample kernel
+        float kl = 0.f;
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq)
+            if (lane + 64 * qq < a.D) kl += klp[(es * 4 + qq) * 64 + lane];
+        kl = wave_sum(kl);
+        if (lane == 0) a.kl_out[b] = kl / (float)a.D;
+    }
+    // ---- dense: out(b, n) = sum_k zd(b, k) * wd(n, k); rows of the MFMA tile = samples (DH_G of 16 used)
+    f32x4_t accd[DH_NBW];
+#pragma unroll
+    for (int i = 0; i < DH_NBW; ++i) accd[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    if (wave * 16 < p.Nd) {
+#pragma unroll
+        for (int s2 = 0; s2 < DH_KSD; ++s2) {
+            if (s2 < ksd) {
+                const uint4 af = *(const uint4*)(zd_img + r * p.Kd + 32 * s2 + 8 * g);
+#pragma unroll
+                for (int i = 0; i < DH_NBW; ++i)
+                    accd[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af), __builtin_bit_cast(bf16x8_t, bd[i][s2]), accd[i], 0, 0, 0);
+            }
+        }
+    }
+    DH_T(5);
+    // epilogue (c1v_epilogue: bias, relu, (t, c) = divmod(n, reshape_w)) into the image; accd[i][e] = out(sample 4 g + e, n)
+    if (g == 0) {
+#pragma unroll
+        for (int i = 0; i < DH_NBW; ++i) {
+            const int n = (wave + DH_W * i) * 16 + r;
+            if (n < p.Nd && t_d[i] < p.xd_len) {
+                const int o = (p.xd_off + t_d[i]) * p.xd_cp + c_d[i];
+#pragma unroll
+                for (int e = 0; e < DH_G; ++e) {
+                    float v = accd[i][e] + bias_dv[i];
+                    if (p.relu_d) v = fmaxf(v, 0.0f);
+                    x_img[e * p.pitch * p.xd_cp + o] = f32_to_bf16(v);
+                }
+            }
+        }
+    }
+    DH_T(6);
+    dh_barrier();
+    // the valid rows of the image -> the buffer (the backward pass reads it): whole rows, the channels behind reshape_w are zero
+    {
+        const int pr = p.xd_cp >> 3;                             // 16-byte pieces per row
+        const int per = p.xd_len * pr, total = DH_G * per;
+        for (int i = tid; i < total; i += 64 * DH_W) {
+            const int e = i / per, q2 = i - e * per;
+            const int o = (e * p.pitch + p.xd_off) * p.xd_cp + 8 * q2;       // (rows of a sample are contiguous: piece q2 of them)
+            if (b0 + e < a.B)
+                *(uint4*)(p.xd + (int64_t)(b0 + e) * p.xd_bstride + p.xd_off * p.xd_cp + 8 * q2) = *(const uint4*)(x_img + o);
+        }
+    }
+    DH_T(7);
+    // ---- transposed convolution = convolution over the zero-bordered image: GEMM row m = e * n_rows + u, K = taps x channels
+    const int rows_c = DH_G * p.n_rows;
+    const int cb = wave & 7, rb0 = wave >> 3;
+    f32x4_t accc[DH_RBW];
+#pragma unroll
+    for (int jb = 0; jb < DH_RBW; ++jb) accc[jb] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    if (cb * 16 < p.F) {
+#pragma unroll
+        for (int jb = 0; jb < DH_RBW; ++jb) {
+            const int rb = rb0 + 2 * jb;
+            if (rb * 16 < rows_c) {
+                int mr = rb * 16 + r;
+                if (mr >= rows_c) mr = rows_c - 1;
+                const int e = mr / p.n_rows, u = mr - e * p.n_rows;
+                const bf16_raw* arow = x_img + (e * p.pitch + u) * p.xd_cp + 8 * g;      // the window starts at buffer row u
+#pragma unroll
+                for (int s2 = 0; s2 < DH_KSC; ++s2) {
+                    if (s2 < ksc) {
+                        const uint4 af = *(const uint4*)(arow + 32 * s2);
+                        accc[jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af), __builtin_bit_cast(bf16x8_t, bc[s2]), accc[jb], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    DH_T(8);
+    {
+        const int f = cb * 16 + r;
+        if (f < p.F) {
+#pragma unroll
+            for (int jb = 0; jb < DH_RBW; ++jb)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int mr = (rb0 + 2 * jb) * 16 + 4 * g + e;
+                    if (mr < rows_c) {
+                        float v = accc[jb][e] + bias_cv;
+                        if (p.relu_c) v = fmaxf(v, 0.0f);
+                        park[mr * p.F + f] = f32_to_bf16(v);
+                    }
+                }
+        }
+    }
+    DH_T(9);
+    dh_barrier();
+    // C1V_ROW_UP2: output row t of a sample = convolution row t / 2 (rows behind 2 * n_rows are not written)
+    {
+        const int pr = p.F >> 3;
+        const int per = p.xf_len * pr, total = DH_G * per;
+        for (int i = tid; i < total; i += 64 * DH_W) {
+            const int e = i / per, q2 = i - e * per;
+            const int t = q2 / pr, pc = q2 - t * pr, u = t >> 1;
+            if (b0 + e < a.B && u < p.n_rows)
+                *(uint4*)(p.xf + (int64_t)(b0 + e) * p.xf_bstride + (int64_t)(p.xf_off + t) * p.xf_cp + 8 * pc) =
+                    *(const uint4*)(park + (e * p.n_rows + u) * p.F + 8 * pc);
+        }
+    }
+#ifdef DH_STAMP
+    DH_T(10);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    DH_T(11);
+    if (tid == 0 && blockIdx.x < 1024) for (int i = 0; i < 12; ++i) dh_dbg[blockIdx.x * 16 + i] = stamp[i];
+#endif
+}
+
+static int dec_head_fill(const c1v_dec_head_args* a, DecHeadDev& p) {
+    C1V_REQUIRE(a && a->latent && a->dense && a->deconv, "dec_head_fwd: null argument");
+    const c1v_latent_args& l = *a->latent;
+    const c1v_dense_args& d = *a->dense;
+    const c1v_conv1d_args& c = *a->deconv;
+    C1V_REQUIRE(l.mlv && l.eps && l.zd_out && l.B > 0 && l.D > 0 && l.ldz >= l.D && l.keep_prob > 0.f, "dec_head_fwd: bad latent arguments");
+    C1V_REQUIRE(l.dtype == C1V_BF16 && d.dtype == C1V_BF16 && c.x.dtype == C1V_BF16, "dec_head_fwd: bf16 operands only");
+    C1V_REQUIRE(l.D <= 256 && l.n_parts <= 8 && (l.n_parts <= 1 || l.part_stride > 0), "dec_head_fwd: latent_dim <= 256 and at most 8 partial slabs");
+    C1V_REQUIRE(d.a == l.zd_out && d.lda == l.ldz && d.rows == l.B && d.K == d.lda, "dec_head_fwd: the dense operand must be the latent head's zd rows");
+    C1V_REQUIRE(d.K % 32 == 0 && d.K <= 32 * DH_KSD && d.ldw >= d.K && d.w_op && d.k_splits <= 1 && d.n_out > 0 && d.n_out <= 16 * DH_W * DH_NBW,
+                "dec_head_fwd: dense shape (K %d, n_out %d) outside the fused kernel's limits", d.K, d.n_out);
+    const c1v_epilogue& ed = d.epi;
+    C1V_REQUIRE(ed.row_mode == C1V_ROW_STORE && ed.reshape_w > 0 && ed.act.data == nullptr && ed.keep == nullptr && ed.sel == nullptr &&
+                ed.dst.dtype == C1V_BF16 && ed.bias_row_w >= 0 && ed.bias_row_w <= ed.reshape_w, "dec_head_fwd: dense epilogue must be a reshaping bf16 STORE");
+    C1V_REQUIRE(ed.dst.data == c.x.data && ed.dst.bstride == c.x.bstride && ed.dst.cp == c.x.cp && ed.dst.off == c.x.off && ed.dst.batch == l.B && c.x.batch == l.B,
+                "dec_head_fwd: the dense epilogue must write the transposed convolution's input buffer");
+    C1V_REQUIRE(ed.reshape_w <= ed.dst.cp && d.n_out <= ed.dst.len * ed.reshape_w, "dec_head_fwd: dense rows do not fit the buffer");
+    C1V_REQUIRE(c.w_op && c.k >= 1 && c.a_off == 0 && c.x.off == c.k - 1 && c.n_rows > 0 && c.x.cp % 32 == 0 && c.k * c.x.cp <= 32 * DH_KSC &&
+                c.ldw >= (int64_t)c.k * c.x.cp && c.n_out > 0 && c.n_out % 8 == 0 && c.n_out <= 128 && DH_G * c.n_rows <= 32 * DH_RBW,
+                "dec_head_fwd: transposed convolution (k %d, cp %d, n_rows %d, n_out %d) outside the fused kernel's limits", c.k, c.x.cp, c.n_rows, c.n_out);
+    const int pitch = (int)(c.x.bstride / c.x.cp);
+    C1V_REQUIRE(c.x.bstride % c.x.cp == 0 && c.n_rows + c.k - 1 <= pitch && ed.dst.off + ed.dst.len <= pitch, "dec_head_fwd: window overruns the sample pitch");
+    const c1v_epilogue& ec = c.epi;
+    C1V_REQUIRE(ec.row_mode == C1V_ROW_UP2 && ec.reshape_w <= 0 && ec.act.data == nullptr && ec.keep == nullptr && ec.sel == nullptr &&
+                ec.dst.dtype == C1V_BF16 && ec.dst.data && ec.dst.cp >= c.n_out && ec.dst.cp % 8 == 0 && ec.dst.bstride % 8 == 0 &&
+                ((uintptr_t)ec.dst.data % 16) == 0 && ec.dst.batch == l.B, "dec_head_fwd: the transposed convolution's epilogue must be a bf16 UP2 store");
+    C1V_REQUIRE(((uintptr_t)d.w_op % 16) == 0 && ((uintptr_t)c.w_op % 16) == 0 && d.ldw % 8 == 0 && c.ldw % 8 == 0 && ((uintptr_t)c.x.data % 16) == 0 &&
+                c.x.bstride % 8 == 0, "dec_head_fwd: operands must be 16-byte aligned");
+    p = DecHeadDev{};
+    p.lat = l;
+    p.wd = (const bf16_raw*)d.w_op; p.ldwd = d.ldw; p.Kd = d.K; p.Nd = d.n_out; p.reshape_w = ed.reshape_w; p.bias_row_w = ed.bias_row_w;
+    p.relu_d = ed.relu; p.bias_d = ed.bias;
+    p.xd = (bf16_raw*)c.x.data; p.xd_bstride = c.x.bstride; p.xd_off = ed.dst.off; p.xd_len = ed.dst.len; p.xd_cp = c.x.cp; p.pitch = pitch;
+    p.wc = (const bf16_raw*)c.w_op; p.ldwc = c.ldw; p.k = c.k; p.n_rows = c.n_rows; p.F = c.n_out; p.relu_c = ec.relu; p.bias_c = ec.bias;
+    p.xf = (bf16_raw*)ec.dst.data; p.xf_bstride = ec.dst.bstride; p.xf_off = ec.dst.off; p.xf_len = ec.dst.len; p.xf_cp = ec.dst.cp;
+    p.lds_img = 16 * p.Kd * 2;
+    p.lds_park = p.lds_img + (int)c1v_cdiv((int64_t)DH_G * pitch * p.xd_cp * 2, 16) * 16;
+    p.lds_kl = p.lds_park + (int)c1v_cdiv((int64_t)DH_G * p.n_rows * p.F * 2, 16) * 16;
+    p.lds_total = p.lds_kl + DH_G * 4 * 64 * 4;
+    C1V_REQUIRE(p.lds_total <= 64 * 1024, "dec_head_fwd: %d bytes of LDS", p.lds_total);
+    return 0;
+}
+extern "C" int c1v_dec_head_fwd_check(const c1v_dec_head_args* a) {
+    DecHeadDev p;
+    return dec_head_fill(a, p);
+}
+extern "C" int c1v_dec_head_fwd(const c1v_dec_head_args* a, void* stream) {
+    DecHeadDev p;
+    if (dec_head_fill(a, p)) return -1;
+    hipLaunchKernelGGL(dec_head_fwd_kernel, dim3((unsigned)c1v_cdiv(p.lat.B, DH_G)), dim3(64 * DH_W), p.lds_total, (hipStream_t)stream, p);
     C1V_LAUNCH_CHECK();
     return 0;
 }

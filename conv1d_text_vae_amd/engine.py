@@ -433,8 +433,33 @@ class VAEEngine:
             rc = f(ref, self._stream())
             if rc != 0:
                 L.check(rc, fn)
-        run.c_fn, run.c_args = f, args                   # what c1v_run_list needs to issue this op natively
+        run.c_fn, run.c_args, run.c_name = f, args, fn   # what c1v_run_list needs to issue this op natively
         return run
+
+    def _fused_head(self, ops):
+        """`ops` with every run [c1v_latent_head_fwd, c1v_dense_fwd, c1v_deconv1d_fwd] that the library's fused kernel takes
+        (c1v_dec_head_fwd_check: bf16, small shapes) replaced by ONE c1v_dec_head_fwd launch -- at C2 three launches of 6.4 +
+        6.1 + 5.2 us that are nearly all latency.  Bit-identical.  The recorded forms of a step (list, graph) go through
+        this; op lists run one by one from Python do not.  C1V_DEC_HEAD_FUSE=0: never."""
+        if os.environ.get('C1V_DEC_HEAD_FUSE', '1') == '0' or len(ops) < 3:
+            return list(ops)
+        key = tuple(id(o) for o in ops)
+        hit = self._head_cache.get(key)
+        if hit is not None:
+            return hit[1]
+        names = [getattr(o, 'c_name', None) for o in ops]
+        out, i = [], 0
+        while i < len(ops):
+            if names[i:i + 3] == ['c1v_latent_head_fwd', 'c1v_dense_fwd', 'c1v_deconv1d_fwd']:
+                a = L.DecHeadArgs(C.pointer(ops[i].c_args), C.pointer(ops[i + 1].c_args), C.pointer(ops[i + 2].c_args))
+                if self.lib.c1v_dec_head_fwd_check(C.byref(a)) == 0:
+                    out.append(self._op('c1v_dec_head_fwd', a))
+                    i += 3
+                    continue
+            out.append(ops[i])
+            i += 1
+        self._head_cache[key] = (list(ops), out)             # (the key's ops are kept alive: ids stay unique)
+        return out
 
     # ---- BatchNormalization ops (use_batch_norm=True) ------------------------------------------------------------
     def _bn_args(self, name: str, x: Buf, mode: int, grad: Optional[L.Seq] = None, dst: Optional[L.Seq] = None, sel=None,
@@ -511,6 +536,7 @@ class VAEEngine:
         self._keep = []
         self._graphs = {}
         self._lists = {}
+        self._head_cache = {}
         op = self._op
         # ---- encoder forward (train / inference differ only in the dropout mask of the last layer)
         self._pack_in_args = L.PackInputArgs(self.x_in.data_ptr(), g.input_text_size, g.input_vector_size, self.Xe[0].seq())
@@ -1130,6 +1156,9 @@ class VAEEngine:
             else:
                 put(o, L.LIST_JOIN if join_next else 0)
                 join_next = False
+        if not any(flags):
+            out = self._fused_head(out)
+            flags = [0] * len(out)
         self._list_blockers = [getattr(o, '__name__', repr(o)) for o in out if not hasattr(o, 'c_fn')]    # (diagnostic)
         return (out, flags) if not self._list_blockers else None
 
@@ -1171,6 +1200,7 @@ class VAEEngine:
         attribute calls happen outside the capture)."""
         gr = self._graphs.get(key)
         if gr is None:
+            ops = self._fused_head(ops)
             torch.cuda.synchronize(self.dev)
             saved = self._save_state()
             self._saved_for_capture = saved

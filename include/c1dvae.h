@@ -274,6 +274,21 @@ typedef struct c1v_latent_args {
 int c1v_latent_head_fwd(const c1v_latent_args*, void* stream);
 int c1v_latent_head_bwd(const c1v_latent_args*, void* stream);
 
+/* latent head -> decoder dense -> first transposed convolution (:1246-1261) in ONE launch, for small batches: as three
+ * launches they are 6.4 + 6.1 + 5.2 us at C2, nearly all of it launch and memory latency.  The arguments are those of the
+ * three entry points (c1v_latent_head_fwd, c1v_dense_fwd, c1v_deconv1d_fwd), linked as the model links them: dense->a is
+ * latent->zd_out, the dense epilogue (reshaping bf16 STORE) writes deconv->x, the deconv epilogue is a bf16 UP2 store.  Every
+ * output of the three launches is written (the backward pass reads them), bit for bit the same.  bf16 only, shapes within
+ * the kernel's limits (latent_dim <= 256, <= 8 partial slabs; dense K <= 256 and n_out <= 512; k * cp <= 128, n_out <= 128, n_rows <= 32):
+ * c1v_dec_head_fwd_check returns 0 if a combination qualifies, without launching.  No counterpart in the reference. */
+typedef struct c1v_dec_head_args {
+    const c1v_latent_args* latent;
+    const c1v_dense_args*  dense;
+    const c1v_conv1d_args* deconv;
+} c1v_dec_head_args;
+int c1v_dec_head_fwd(const c1v_dec_head_args*, void* stream);
+int c1v_dec_head_fwd_check(const c1v_dec_head_args*);
+
 /* ---- a8: cosine-softmax cross-entropy against the vocabulary matrix (:1193-1203, :1319, :1326) --------------
  * Step 1  c1v_l2norm_rows: yhat = y / sqrt(max(sum y^2, 1e-12)) * qscale  -> T [M][kp] (zero padded), rnorm[M]
  * Step 2  c1v_cos_softmax_accum: for every row m and vocabulary row n:  e = exp2(yhat_m . w_n)   (qscale = log2(e)/tau)

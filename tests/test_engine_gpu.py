@@ -35,6 +35,8 @@ CASES = {
     'kp320': dict(B=6, T_in=14, T_out=13, E=316, n_filters=(64,), k=3, D=12, N=300),   # V = 318: the widest fused row (kp = 320), whole-row out conv in bf16
     'ragged': dict(B=37, T_in=11, T_out=9, E=62, n_filters=(64,), k=3, D=8, N=150),    # 37 samples x odd lengths: whole-row tiles straddle samples and end ragged
     'longflat': dict(B=8, T_in=70, T_out=20, E=30, n_filters=(64,), k=3, D=16, N=90),   # flat = 2176: split-K heads GEMM (8 slabs)
+    'k4f16': dict(B=5, T_in=15, T_out=14, E=12, n_filters=(16,), k=4, D=12, N=40),     # 4 taps, 5 samples (fused decoder head: 4 per workgroup)
+    'k2f24': dict(B=7, T_in=13, T_out=12, E=20, n_filters=(24, 8), k=2, D=70, N=60),   # 2 taps, two layers, latent_dim > 64
 }
 
 
@@ -408,6 +410,42 @@ def test_all_weight_gradients_in_one_launch_are_bit_identical(name, dtype, monke
         for k_, v in got['0'][0].items():
             np.testing.assert_array_equal(got[mode][0][k_], v, err_msg=k_)
         np.testing.assert_array_equal(got[mode][2], got['0'][2], err_msg=mode)
+
+
+@pytest.mark.parametrize('name', ['tiny1', 'k4f16', 'k2f24', 'mid', 'wide', 'ragged', 'longflat', 'big128'])
+def test_decoder_head_in_one_launch_is_bit_identical(name, monkeypatch):
+    """c1v_dec_head_fwd (latent head -> decoder dense -> first transposed convolution in ONE launch) against the three launches
+    it replaces, in the recorded step and in the recorded inference / validation passes (no dropout mask there): every buffer
+    the three write, the loss, the gradients and a three-step Nadam trajectory agree to the bit.  Batches that are not a
+    multiple of the kernel's four samples per workgroup, one and several partial slabs of the heads GEMM, 2 to 4 taps."""
+    c = CASES[name]
+    og, params, Wv, x, ids, eps, mask_e, mask_d = make_case(c)
+    got = {}
+    for mode in ('1', '0'):
+        monkeypatch.setenv('C1V_DEC_HEAD_FUSE', mode)
+        eng = build_engine(c, og, params, Wv, 'bf16')
+        load_fixed(eng, x, ids, eps, mask_e, mask_d)
+        eng.train_step(use_graph=True, fixed_rng=True)
+        torch.cuda.synchronize()
+        names = [getattr(o, 'c_name', '') for o in eng._lists['train_fixed'][3]]
+        if mode == '1' and 'c1v_dec_head_fwd' not in names:
+            pytest.skip('this shape is outside the fused kernel\'s limits')
+        assert ('c1v_dec_head_fwd' in names) == (mode == '1') and ('c1v_latent_head_fwd' in names) == (mode == '0')
+        bufs = {'Xd0': eng.Xd[0].t, 'Xnext': (eng.Xd[1] if len(eng.Xd) > 1 else eng.Xf).t, 'zd': eng.zd, 'mlv': eng.mlv,
+                'z_out': eng.z_out, 'kl_b': eng.kl_b, 'grads': eng.grads, 'loss': eng.loss_out}
+        train = {k_: v.float().cpu().numpy().copy() for k_, v in bufs.items()}
+        for _ in range(2):
+            eng.train_step(use_graph=True, fixed_rng=True)
+        eng.eval_step(use_graph=True, fixed_rng=True)
+        torch.cuda.synchronize()
+        evalb = {k_: bufs[k_].float().cpu().numpy().copy() for k_ in ('Xd0', 'Xnext', 'zd', 'z_out', 'kl_b', 'loss')}
+        y = eng.reconstruct(postprocess=False).float().cpu().numpy().copy()
+        got[mode] = (train, evalb, y, eng.params.cpu().numpy().copy())
+    for part in (0, 1):
+        for k_, v in got['0'][part].items():
+            np.testing.assert_array_equal(got['1'][part][k_], v, err_msg='%s (%s)' % (k_, ('train', 'eval')[part]))
+    np.testing.assert_array_equal(got['1'][2], got['0'][2])
+    np.testing.assert_array_equal(got['1'][3], got['0'][3])
 
 
 @pytest.mark.parametrize('name', ['mid', 'wide', 'big128', 'kp320', 'ragged'])
