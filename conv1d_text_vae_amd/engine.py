@@ -440,8 +440,11 @@ class VAEEngine:
         """`ops` with every run [c1v_latent_head_fwd, c1v_dense_fwd, c1v_deconv1d_fwd] that the library's fused kernel takes
         (c1v_dec_head_fwd_check: bf16, small shapes) replaced by ONE c1v_dec_head_fwd launch -- at C2 three launches of 6.4 +
         6.1 + 5.2 us that are nearly all latency.  Bit-identical.  The recorded forms of a step (list, graph) go through
-        this; op lists run one by one from Python do not.  C1V_DEC_HEAD_FUSE=0: never."""
-        if os.environ.get('C1V_DEC_HEAD_FUSE', '1') == '0' or len(ops) < 3:
+        this; op lists run one by one from Python do not.  C1V_DEC_HEAD_FUSE=0: never; C1V_DEC_HEAD_MAX_BATCH: largest batch."""
+        # (small batches only: a workgroup carries four samples and fetches both weight operands for them, so beyond one
+        # workgroup per CU the GEMM kernels, which share a weight tile among 64 rows, are the better form)
+        if os.environ.get('C1V_DEC_HEAD_FUSE', '1') == '0' or len(ops) < 3 or \
+                self.B > int(os.environ.get('C1V_DEC_HEAD_MAX_BATCH', '1024')):
             return list(ops)
         key = tuple(id(o) for o in ops)
         hit = self._head_cache.get(key)

@@ -421,6 +421,7 @@ def test_decoder_head_in_one_launch_is_bit_identical(name, monkeypatch):
     c = CASES[name]
     og, params, Wv, x, ids, eps, mask_e, mask_d = make_case(c)
     got = {}
+    monkeypatch.setenv('C1V_DEC_HEAD_MAX_BATCH', '1000000')         # (big128: several rounds of workgroups; the engine stops at 1024)
     for mode in ('1', '0'):
         monkeypatch.setenv('C1V_DEC_HEAD_FUSE', mode)
         eng = build_engine(c, og, params, Wv, 'bf16')
