@@ -396,12 +396,12 @@ __global__ __launch_bounds__(64 * DH_W) void dec_head_fwd_kernel(const DecHeadDe
             const int t = nc / p.reshape_w, c = nc - t * p.reshape_w;
             t_d[i] = t; c_d[i] = c;
             const int bi = p.bias_row_w > 0 ? t * p.bias_row_w + (c < p.bias_row_w ? c : p.bias_row_w - 1) : nc;
-            bias_dv[i] = bdp[bi];
+            bias_dv[i] = bdp[p.bias_d ? bi : 0];             // (no bias: one readable float, ignored)
             if (!p.bias_d || (p.bias_row_w > 0 && c >= p.bias_row_w)) bias_dv[i] = 0.f;
         }
         const float* bcp = p.bias_c ? p.bias_c : a.eps;
         const int f = (wave & 7) * 16 + r;
-        bias_cv = bcp[f < p.F ? f : p.F - 1];
+        bias_cv = bcp[p.bias_c ? (f < p.F ? f : p.F - 1) : 0];
         if (!p.bias_c) bias_cv = 0.f;
     }
     // both weight operands as MFMA fragments (lane (r, g): operand row = column block * 16 + r, 8 K values from 8 g), in the
