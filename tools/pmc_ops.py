@@ -29,6 +29,11 @@ def op_list(eng, g):
             ops.append(('live_rows', eng.ops_live_rows[0]))
     fwd = list(eng.ops_enc_train) + list(eng.ops_lat_train) + list(eng.ops_dec)
     fnames = names[:nl + 1] + ['latent_fwd'] + names[nl + 1:]
+    fused = eng._fused_head(fwd)
+    if len(fused) == len(fwd) - 2:                             # latent head + decoder dense + first deconv in one launch (small batches)
+        i = fnames.index('latent_fwd')
+        fnames = fnames[:i] + ['dec_head (latent + dec_dense + deconv1)'] + fnames[i + 3:]
+        fwd = fused
     ops += [(n + ' fwd' if n != 'latent_fwd' else n, o) for n, o in zip(fnames, fwd)]
     core = eng.ops_loss_train_core
     ops += list(zip(['l2norm', 'vocab_stream', 'xent_finish'][-len(core):], core))
