@@ -388,3 +388,48 @@ def test_live_row_table_of_the_large_batch_launch(M):
     got = dst[:Bg * 8 * cp].float().cpu().numpy().reshape(Bg, 8, cp)[:, 1:1 + Tg, :Cg]
     want = np.where(gid.cpu().numpy()[:, :, None] >= 0, table.cpu().numpy()[np.maximum(gid.cpu().numpy(), 0)], 0.0)
     np.testing.assert_allclose(got, want, rtol=2 ** -8, atol=0)
+
+
+@pytest.mark.gpu
+def test_recorded_list_stops_at_a_failing_entry_and_stays_ordered():
+    """c1v_run_list / c1v_run_list_fork (the recorded step; no counterpart in the reference): the first failing entry ends the
+    list with its return code and its error text, later entries are not issued, and what was already issued on the second
+    stream is joined, so that synchronising the main stream covers it."""
+    from conv1d_text_vae_amd import _lib as L
+    lib = L.load()
+    dev = torch.device('cuda:0')
+    B, D = 8, 16
+    g = torch.Generator(device='cpu').manual_seed(5)
+    mlv = torch.randn(B, 2 * D, generator=g).to(dev)
+    eps = torch.randn(B, D, generator=g).to(dev)
+    zd = torch.zeros(B, 64, device=dev)
+    z = [torch.full((B, D), -7.0, device=dev) for _ in range(3)]
+
+    def latent(rows, z_out):
+        return L.LatentArgs(mlv.data_ptr(), rows, D, eps.data_ptr(), None, 0.7, 1.0, zd.data_ptr(), L.F32, 64, z_out.data_ptr(), None,
+                            None, B, None, 0, 1, 0)
+    items = [latent(B, z[0]), latent(0, z[1]), latent(B, z[2])]          # the second one fails its shape check
+    n = len(items)
+    fns = (C.c_void_p * n)(*[C.cast(lib.c1v_latent_head_fwd, C.c_void_p)] * n)
+    args = (C.c_void_p * n)(*[C.cast(C.pointer(a), C.c_void_p) for a in items])
+    want = (mlv[:, :D] + torch.exp(mlv[:, D:]) * eps).cpu().numpy()
+    main = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    side = torch.cuda.Stream(dev)
+    for forked in (False, True):
+        for t in z:
+            t.fill_(-7.0)
+        torch.cuda.synchronize()
+        if forked:
+            flags = (C.c_int32 * n)(L.LIST_SIDE | L.LIST_FORK, 0, 0)
+            rc = lib.c1v_run_list_fork(n, fns, args, flags, main, C.c_void_p(side.cuda_stream))
+        else:
+            rc = lib.c1v_run_list(n, fns, args, main)
+        assert rc != 0 and b'latent_head_fwd' in lib.c1v_last_error()
+        torch.cuda.current_stream(dev).synchronize()              # (the main stream only: the side entry must have been joined)
+        np.testing.assert_allclose(z[0].cpu().numpy(), want, rtol=1e-6, atol=1e-6)
+        assert float(z[1].min()) == -7.0 and float(z[2].max()) == -7.0
+    # and a complete list returns 0
+    ok = (C.c_void_p * 2)(args[0], args[2])
+    assert lib.c1v_run_list(2, fns, ok, main) == 0
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(z[2].cpu().numpy(), want, rtol=1e-6, atol=1e-6)
