@@ -43,7 +43,9 @@ def test_ctypes_struct_sizes_match_the_header(tmp_path):
                'c1v_nadam_args': _lib.NadamArgs, 'c1v_vocab_argmax_args': _lib.VocabArgmaxArgs,
                'c1v_rng_desc': _lib.RngDesc, 'c1v_bn_args': _lib.BnArgs,
                'c1v_vocab_argmax_noalloc_args': _lib.VocabArgmaxNoallocArgs,
-               'c1v_grad_finalize_args': _lib.GradFinalizeArgs}
+               'c1v_grad_finalize_args': _lib.GradFinalizeArgs, 'c1v_dec_head_args': _lib.DecHeadArgs,
+               'c1v_wgrad_batch_args': _lib.WgradBatchArgs, 'c1v_live_rows_args': _lib.LiveRowsArgs,
+               'c1v_loss_reduce_args': _lib.LossReduceArgs}
     prog = '#include <stdio.h>\n#include "c1dvae.h"\nint main(void){\n'
     for name in structs:
         prog += '  printf("%s %%zu\\n", sizeof(%s));\n' % (name, name)
@@ -88,3 +90,35 @@ def test_engine_refuses_to_run_without_gpu():
     g = geometry.Geometry(12, 12, 10, 10, (6,), 3, 5)
     with pytest.raises(_lib.C1VError):
         engine.VAEEngine(g, 4)
+
+
+def test_fused_decoder_head_check_accepts_and_refuses_on_the_host():
+    """c1v_dec_head_fwd_check launches nothing: it only says whether the three linked ops are within the fused kernel's limits
+    (the engine falls back to the three launches otherwise).  The C2 shapes qualify; other operand types, a dense operand that is
+    not the latent head's output, too many taps x channels, and filter counts that are not whole 16-byte rows do not."""
+    lib = _lib.load()
+    L = _lib
+    B, D, Dp, n_t, width, width_p, k, F, To = 256, 256, 256, 15, 18, 20, 3, 128, 32
+    mem = (C.c_char * (1 << 16))()
+    base = (C.addressof(mem) + 255) & ~255               # (only addresses and alignment are looked at)
+    zd, xd, xf, wd, wc, bias = base, base + 4096, base + 8192, base + 12288, base + 16384, base + 20480
+
+    def case(dtype=L.BF16, a=zd, cp=32, taps=k, n_out=F):
+        lat = L.LatentArgs(base, B, D, base, None, 0.7, 1.0, zd, dtype, Dp, None, None, None, B, None, 0, 8, B * 2 * D)
+        pitch = n_t + 3 * (taps - 1) + ((n_t + 3 * (taps - 1)) & 1)
+        xd_seq = L.Seq(xd, dtype, B, pitch * cp, taps - 1, n_t, cp, width)
+        e_d = L.Epilogue(bias, 1, L.ROW_STORE, width_p, xd_seq, L.Seq(), 1, 1.0, None, 0, 0, None, 1.0, bias_row_w=width)
+        dense = L.DenseArgs(a, dtype, B, Dp, Dp, wd, Dp, n_t * width_p, e_d)
+        xf_seq = L.Seq(xf, dtype, B, (To + 4) * 128, 1, To, 128, n_out)
+        e_c = L.Epilogue(bias, 1, L.ROW_UP2, 0, xf_seq, L.Seq(), 1, 1.0, None, 0, 0, None, 1.0)
+        conv = L.ConvArgs(xd_seq, 0, n_t + taps - 1, taps, wc, 128, n_out, e_c)
+        keep = (lat, dense, conv)
+        return L.DecHeadArgs(C.pointer(lat), C.pointer(dense), C.pointer(conv)), keep
+
+    args, keep = case()
+    assert lib.c1v_dec_head_fwd_check(C.byref(args)) == 0, lib.c1v_last_error()
+    for kw, text in ((dict(dtype=L.F32), b'bf16'), (dict(a=zd + 512), b'latent'), (dict(cp=64), b'limits'), (dict(n_out=100), b'limits')):
+        args, keep = case(**kw)
+        assert lib.c1v_dec_head_fwd_check(C.byref(args)) != 0, kw
+        assert text in lib.c1v_last_error(), (kw, lib.c1v_last_error())
+    assert lib.c1v_dec_head_fwd_check(None) != 0
