@@ -773,7 +773,9 @@ class VAEEngine:
         # short dgrad tiles: about 192 of them (under one per CU) is best, more only lengthens the longest CU's queue (a
         # 512-channel layer went from 32 splits = 1536 workgroups to 4 splits: 124 -> 72 us).  A wgrad launched alone (the
         # first convolution) wants both slots of every CU: just under 512 (one workgroup over a full round doubles the time).
-        wgrad_wgs = int(os.environ.get('C1V_WGRAD_WGS', '192'))
+        # (round 3, after the wgrad epilogue through LDS and the XCD-aware deal of its workgroups: 320-384 is 0.7 % of the C4 step
+        # better than 192 -- alternating runs on one box, 6.573 / 6.581 ms against 6.624 -- and 448+ is worse again)
+        wgrad_wgs = int(os.environ.get('C1V_WGRAD_WGS', '320'))
         wgrad_wgs_alone = int(os.environ.get('C1V_WGRAD_WGS_ALONE', '512'))
         wgrad_max = int(os.environ.get('C1V_WGRAD_MAX_SPLITS', '128'))
 
